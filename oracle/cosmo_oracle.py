@@ -1,0 +1,801 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (numpy) of the reference hot path.
+
+This module is the *checker* for the HIP path.  It is imported only by tests/,
+by __graft_entry__.smoke() and by the cpu_baseline leg of bench.py; the product
+package (cosmo_pol_amd) never imports it.
+
+Every function cites the reference file:line it restates (paths relative to the
+reference root).  The arithmetic mirrors the reference running under NumPy >= 2
+(NEP-50 promotion): expression structure and operand dtypes are kept so that the
+results agree with the reference run in the build container to f32 round-off; the
+oracle is pinned by tests/golden/*.npz, which were produced by running the
+reference itself (tests/golden/make_golden.py).
+
+Parity status of the pieces that are third-party in the reference:
+  * WGS84 direct geodesic (pyproj Geod.fwd, interpolation/interpolation.py:316-325):
+    restated in oracle_c.c (Karney series), pinned by tests/golden/ex_bemas.npz.
+  * rotated-pole transform (pycosmo.WGS_to_COSMO, interpolation/interpolation.py:355):
+    the source is absent from the reference snapshot -> PARITY UNPINNED; the
+    standard COSMO rotated-pole formula is used.
+"""
+import copy
+import math
+
+import numpy as np
+import scipy.special as spe
+
+# ----------------------------------------------------------------------------
+# configuration  (utilities/cfg.py:22-51)
+# ----------------------------------------------------------------------------
+DEFAULT_CONFIG = {
+    'radar': {'coords': [46.42563, 6.01, 1672.7], 'type': 'ground', 'frequency': 5.6,
+              'range': 150000, 'radial_resolution': 500, 'PRI': 700, 'FFT_length': 256,
+              'sensitivity': [-5, 10000], '3dB_beamwidth': 1.},
+    'attenuation': {'correction': 1},
+    'refraction': {'scheme': 1},
+    'integration': {'scheme': 1, 'nv_GH': 9, 'nh_GH': 3, 'n_gaussians': 7,
+                    'antenna_diagram': '', 'weight_threshold': 1., 'nr_GH': 7, 'na_GL': 7},
+    'doppler': {'scheme': 1, 'turbulence_correction': 0},
+    'microphysics': {'scheme': 1},
+}
+
+
+def make_config(**sections):
+    cfg = copy.deepcopy(DEFAULT_CONFIG)
+    for sec, kv in sections.items():
+        cfg.setdefault(sec, {}).update(kv)
+    return cfg
+
+
+# ----------------------------------------------------------------------------
+# constants  (constants/constants.py:20-98)
+# ----------------------------------------------------------------------------
+EPS = np.finfo(np.float32).eps          # constants.py:25
+C_LIGHT = 299792458.                    # constants.py:34
+RHO_W = 1000. / (1000 ** 3)             # constants.py:35
+KW = 0.93                               # constants.py:41
+SIMULATED_VARIABLES = ['ZH', 'DSPECTRUM', 'RVEL', 'ZV', 'PHIDP', 'ZDR', 'RHOHV', 'KDP']  # :26
+
+
+def radar_constants(cfg):
+    """constants/constants.py:70-90 (radar-derived values)."""
+    r = cfg['radar']
+    out = {}
+    out['NVEL'] = C_LIGHT / (4 * 1E-6 * r['PRI'] * r['frequency'] * 1E09)
+    out['VRES'] = 2 * out['NVEL'] / r['FFT_length']
+    out['VARRAY'] = np.arange(-out['NVEL'], out['NVEL'] + out['VRES'], out['VRES'])
+    out['WAVELENGTH'] = C_LIGHT / (r['frequency'] * 1E09) * 1000
+    out['KW'] = KW
+    out['RANGE_RADAR'] = np.arange(r['radial_resolution'] / 2, r['range'], r['radial_resolution'])
+    return out
+
+
+def _c1():
+    """constants/constants_1mom.py:15-65."""
+    c = {}
+    c['N0_G'] = 4 * 1E3
+    c['B_G'] = 3.1
+    c['A_G'] = 169.6 * (1000 ** -c['B_G'])
+    c['ALPHA_G'] = 442.0 * (1000 ** -0.89)
+    c['BETA_G'] = 0.89
+    c['MU_G'] = 0.0
+    c['LAMBDA_FACTOR_G'] = c['A_G'] * c['N0_G'] * spe.gamma(c['B_G'] + 1)
+    c['VEL_FACTOR_G'] = spe.gamma(c['MU_G'] + c['BETA_G'] + 1)
+    c['NTOT_FACTOR_G'] = spe.gamma(c['MU_G'] + 1)
+    c['B_S'] = 2
+    c['A_S'] = 0.038 / (1000 ** c['B_S'])
+    c['ALPHA_S'] = 4.9 * (1000 ** -0.25)
+    c['BETA_S'] = 0.25
+    c['MU_S'] = 0.0
+    c['LAMBDA_FACTOR_S'] = spe.gamma(c['B_S'] + 1)
+    c['VEL_FACTOR_S'] = spe.gamma(c['MU_S'] + c['BETA_S'] + 1)
+    c['NTOT_FACTOR_S'] = spe.gamma(c['MU_S'] + 1)
+    c['MU_R'] = 0.5
+    n00_r = 8E6 / (1000 ** (1 + c['MU_R'])) * (0.01) ** (-c['MU_R'])
+    c['N0_R'] = 0.1 * n00_r * np.exp(3.2 * c['MU_R'])
+    c['A_R'] = np.pi / 6. * RHO_W
+    c['B_R'] = 3.
+    c['ALPHA_R'] = 130 / np.sqrt(1000)
+    c['BETA_R'] = 0.5
+    c['LAMBDA_FACTOR_R'] = c['A_R'] * c['N0_R'] * spe.gamma(1. + c['B_R'] + c['MU_R'])
+    c['VEL_FACTOR_R'] = spe.gamma(c['MU_R'] + c['BETA_R'] + 1)
+    c['NTOT_FACTOR_R'] = spe.gamma(c['MU_R'] + 1)
+    return c
+
+
+def _c2(c1):
+    """constants/constants_2mom.py:16-149 (incl. the 'to remove' overrides :27,39,61,74)."""
+    c = {}
+    def derive(tag, a_, b_, alpha_, beta_, nu_, mu_, xmin, xmax, b_over=None, a_over=None):
+        b = 1. / b_
+        a = a_ ** (-1 / b_)
+        if b_over is not None:
+            b = b_over
+        beta = beta_ / b_
+        alpha = alpha_ * a_ ** (-beta_ / b_)
+        nu = nu_ / b_
+        mu = (mu_ + 1) / b_ - 1
+        lam_f = 1. / a * spe.gamma((mu + 1) / nu) / spe.gamma((mu + b + 1) / nu)
+        a = a * 1000 ** (-b)
+        if a_over is not None:
+            a = a_over
+        alpha = alpha * 1000 ** (-beta)
+        c.update({'A_' + tag: a, 'B_' + tag: b, 'ALPHA_' + tag: alpha, 'BETA_' + tag: beta,
+                  'NU_' + tag: nu, 'MU_' + tag: mu, 'LAMBDA_FACTOR_' + tag: lam_f,
+                  'VEL_FACTOR_' + tag: spe.gamma((mu + beta + 1) / nu),
+                  'NTOT_FACTOR_' + tag: spe.gamma((mu + 1) / nu),
+                  'X_MIN_' + tag: xmin, 'X_MAX_' + tag: xmax})
+    derive('G', 0.142, 0.314, 86.89371, 0.268325, 1. / 3., 1.0, 1E-09, 5E-04,
+           b_over=c1['B_G'], a_over=c1['A_G'])
+    derive('S', 2.4, 0.455, 4.2, 0.092, 0.5, 0.0, 1E-10, 2E-05,
+           b_over=c1['B_S'], a_over=c1['A_S'])
+    derive('R', 0.124, 1. / 3., 114.0137, 0.23437, 1. / 3., 0.0, 2.6E-10, 3E-06)
+    derive('H', 0.1366, 1. / 3., 39.3, 1. / 6., 1. / 3., 1.0, 2.6E-09, 5E-04)
+    return c
+
+
+D_RANGE = {'R': (0.2, 8), 'S': (0.2, 20), 'G': (0.2, 15), 'H': (0.2, 15)}  # constants_2mom.py:32,67,99,137
+
+
+class Hydro(object):
+    """Parameter record of one hydrometeor class (hydrometeors/hydrometeors.py:177-438)."""
+
+    def __init__(self, kind, scheme):
+        c1 = _c1()
+        c2 = _c2(c1)
+        if kind == 'H':
+            scheme = '2mom'                       # hydrometeors.py:413
+        if scheme not in ('1mom', '2mom'):
+            scheme = '1mom'                       # hydrometeors.py:180-181
+        self.kind, self.scheme = kind, scheme
+        src = c1 if scheme == '1mom' else c2
+        self.d_min, self.d_max = D_RANGE[kind]
+        for low, up in (('a', 'A_'), ('b', 'B_'), ('alpha', 'ALPHA_'), ('beta', 'BETA_'),
+                        ('mu', 'MU_'), ('lambda_factor', 'LAMBDA_FACTOR_'),
+                        ('vel_factor', 'VEL_FACTOR_'), ('ntot_factor', 'NTOT_FACTOR_')):
+            setattr(self, low, src[up + kind])
+        self.nu = 1 if scheme == '1mom' else c2['NU_' + kind]
+        self.N0 = None
+        if scheme == '1mom' and kind == 'R':
+            self.N0 = c1['N0_R']
+        if kind == 'G':
+            self.N0 = c1['N0_G']                  # hydrometeors.py:362 (both schemes)
+        if scheme == '2mom':
+            self.x_min, self.x_max = c2['X_MIN_' + kind], c2['X_MAX_' + kind]
+        self.lambda_ = None
+        self.ntot = None
+
+    # hydrometeors.py:127-155 (2-mom), :247-257 (rain), :311-324 (snow), :379-389 (graupel)
+    def set_psd(self, *args):
+        if len(args) == 2 and self.scheme == '2mom':
+            with np.errstate(divide='ignore', invalid='ignore'):
+                qn = np.squeeze(np.array([args[0]]))
+                q = np.squeeze(np.array([args[1]]))
+                x_mean = np.minimum(np.maximum(q * 1.0 / (qn + EPS), self.x_min), self.x_max)
+                x_mean = np.squeeze(x_mean)
+                lam = np.asarray((self.lambda_factor * x_mean) ** (-self.nu / self.b))
+                lam[q == 0] = float('nan')
+                if lam.shape == ():
+                    lam = np.array([lam])
+                n0 = np.asarray((self.nu / self.ntot_factor) * qn * lam ** ((self.mu + 1) / self.nu))
+                n0 = n0 * 1000 ** (-(1 + self.mu))
+                lam = lam * 1000 ** (-self.nu)
+                self.N0 = n0.T
+                self.lambda_ = lam.T
+                self.ntot = args[0]
+        elif self.scheme == '1mom' and self.kind == 'S':
+            t, q = args
+            self.N0 = 13.5 * (5.65 * 10 ** 5 * np.exp(-0.107 * (t - 273.15))) / 1000
+            with np.errstate(divide='ignore', invalid='ignore'):
+                lam = np.array((self.a * self.N0 * self.lambda_factor / q) ** (1. / (self.b + 1)))
+                lam[q == 0] = float('nan')
+                self.lambda_ = lam
+        elif self.scheme == '1mom':
+            with np.errstate(divide='ignore', invalid='ignore'):
+                lam = np.array((self.lambda_factor / args[0]) ** (1. / (4. + self.mu)))
+                lam[args[0] == 0] = float('nan')
+                self.lambda_ = lam
+
+    # hydrometeors.py:58-64
+    def get_N(self, D):
+        siz = self.lambda_.shape
+        D = np.repeat(D[:, None], siz[0], axis=1)
+        if len(siz) > 1:
+            D = np.repeat(D[:, :, None], siz[1], axis=2)
+        return np.squeeze(self.N0 * D ** self.mu * np.exp(-self.lambda_ * D ** self.nu))
+
+    def get_V(self, D):                            # hydrometeors.py:69-70
+        return self.alpha * D ** self.beta
+
+    def get_D_from_V(self, V):                     # hydrometeors.py:72-73
+        return (1.0 / self.alpha * V) ** (1.0 / self.beta)
+
+    def integrate_V(self):                         # hydrometeors.py:75-81
+        v_int = self.vel_factor * self.N0 * self.alpha / self.nu * \
+            self.lambda_ ** (-(self.beta + self.mu + 1) / self.nu)
+        if self.scheme == '2mom':
+            n_int = self.ntot
+        else:
+            n_int = self.ntot_factor * self.N0 / self.nu * self.lambda_ ** (-(self.mu + 1) / self.nu)
+        return v_int, n_int
+
+
+# ----------------------------------------------------------------------------
+# lookup table  (lookup/lut.py:79-245)
+# ----------------------------------------------------------------------------
+class Lut(object):
+    """Regular 4-D table [e, t, d, sz]; axes stored as float32 (lut.py:112-116)."""
+
+    def __init__(self, e_axis, t_axis, d_axis, table):
+        self.axes_names = {'e': 0, 't': 1, 'd': 2, 'sz': 3}
+        self.axes = [np.asarray(a).astype('float32') for a in
+                     (e_axis, t_axis, d_axis, np.arange(12))]
+        self.axes_limits = [[np.min(a), np.max(a)] for a in self.axes]
+        self.axes_step = [a[1] - a[0] for a in self.axes]
+        self.value_table = np.asarray(table)
+
+    def nearest(self, name, x):
+        """lut.py:240-241 -- nearest node, np.round (half to even), clamped."""
+        ax = self.axes_names[name]
+        closest = np.round((x - self.axes_limits[ax][0]) / self.axes_step[ax])
+        n = self.value_table.shape[ax]
+        return np.minimum(np.maximum(0, closest), n - 1).astype(int)
+
+    def lookup_line(self, e, t):
+        return self.value_table[self.nearest('e', e), self.nearest('t', t)]
+
+
+# ----------------------------------------------------------------------------
+# small helpers  (utilities/utilities.py:18-66)
+# ----------------------------------------------------------------------------
+def nan_cumprod(x):
+    x[np.isnan(x)] = 1
+    return np.cumprod(x)
+
+
+def nan_cumsum(x):
+    x[np.isnan(x)] = 0
+    return np.cumsum(x)
+
+
+def _pad_pair(x, y, cst):
+    x, y = np.array(x), np.array(y)
+    diff = np.array(x.shape) - np.array(y.shape)
+    p1, p2 = [], []
+    for d in diff:
+        if d < 0:
+            p1.append((0, -d)); p2.append((0, 0))
+        else:
+            p2.append((0, d)); p1.append((0, 0))
+    return (np.pad(x, p1, 'constant', constant_values=cst),
+            np.pad(y, p2, 'constant', constant_values=cst))
+
+
+def sum_arr(x, y, cst=0):
+    x, y = _pad_pair(x, y, cst)
+    return np.sum([x, y], axis=0)
+
+
+def nansum_arr(x, y, cst=0):
+    x, y = _pad_pair(x, y, cst)
+    return np.nansum([x, y], axis=0)
+
+
+class Beam(object):
+    """utilities/beam.py:8-18."""
+
+    def __init__(self, values, mask, lats, lons, dist, heights, elev=(), GH_pt=(), GH_weight=1):
+        self.values, self.mask = values, mask
+        self.lats_profile, self.lons_profile = lats, lons
+        self.dist_profile, self.heights_profile = dist, heights
+        self.elev_profile, self.GH_pt, self.GH_weight = elev, GH_pt, GH_weight
+
+
+def fold_elevation(elev):
+    """scatter/scattering_sz.py:66-68 (in place)."""
+    elev[elev > 90] = 180 - elev[elev > 90]
+    elev[elev < 0] = -elev[elev < 0]
+    return elev
+
+
+def hydrom_types(scheme):
+    return ['R', 'S', 'G'] if scheme == 1 else ['R', 'S', 'G', 'H']   # scattering_sz.py:32-35
+
+
+# ----------------------------------------------------------------------------
+# polarimetric observables  (scatter/scattering_sz.py:17-196)
+# ----------------------------------------------------------------------------
+def get_pol_from_sz(sz, wavelength):
+    """scatter/scattering_sz.py:164-196."""
+    xs_h = 2 * np.pi * (sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3])
+    z_h = wavelength ** 4 / (np.pi ** 5 * KW ** 2) * xs_h
+    xs_v = 2 * np.pi * (sz[:, 0] + sz[:, 1] + sz[:, 2] + sz[:, 3])
+    z_v = wavelength ** 4 / (np.pi ** 5 * KW ** 2) * xs_v
+    zdr = xs_h / xs_v
+    kdp = 1e-3 * (180.0 / np.pi) * wavelength * (sz[:, 10] - sz[:, 8])
+    ah = 4.343e-3 * (2 * wavelength * sz[:, 11])
+    av = 4.343e-3 * (2 * wavelength * sz[:, 9])
+    a = (sz[:, 4] + sz[:, 7]) ** 2 + (sz[:, 6] - sz[:, 5]) ** 2
+    b = (sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3])
+    c = (sz[:, 0] + sz[:, 1] + sz[:, 2] + sz[:, 3])
+    with np.errstate(invalid='ignore', divide='ignore'):
+        rhohv = np.sqrt(a / (b * c))
+    delta_hv = np.arctan2(sz[:, 5] - sz[:, 6], -sz[:, 4] - sz[:, 7])
+    return z_h, z_v, zdr, rhohv, kdp, ah, av, delta_hv
+
+
+def integrate_sz(list_beams, luts, cfg):
+    """scatter/scattering_sz.py:24-110: GH-weighted, PSD-integrated 12-component
+    vector per gate (float32, NaN where nothing contributes)."""
+    scheme = cfg['microphysics']['scheme']
+    num_beams = len(list_beams)
+    idx_0 = int(num_beams / 2)
+    len_beams = len(list_beams[idx_0].dist_profile)
+    types = hydrom_types(scheme)
+    sz_integ = np.zeros((len_beams, len(types), 12), dtype='float32')
+    sz_integ.fill(np.nan)
+    for j, h in enumerate(types):
+        hyd = Hydro(h, '2mom' if scheme == 2 else '1mom')
+        lut = luts[h]
+        list_D = lut.axes[lut.axes_names['d']]
+        dD = list_D[1] - list_D[0]
+        for beam in list_beams:
+            for k in beam.values.keys():
+                beam.values[k] = beam.values[k][0:len_beams]
+            valid = beam.values['Q' + h + '_v'] > 0
+            elev = fold_elevation(beam.elev_profile)
+            T = beam.values['T']
+            sz = lut.lookup_line(e=elev[valid], t=T[valid])
+            QM = beam.values['Q' + h + '_v']
+            if scheme == 1:
+                if h != 'S':
+                    hyd.set_psd(QM[valid])
+                else:
+                    hyd.set_psd(T[valid], QM[valid])
+            else:
+                QN = beam.values['QN' + h + '_v']
+                hyd.set_psd(QN[valid], QM[valid])
+            N = hyd.get_N(list_D)
+            if len(N.shape) == 1:
+                N = np.reshape(N, [len(N), 1])
+            sz_psd = np.einsum('ijk,ji->ik', sz, N) * dD
+            sz_integ[valid, j, :] = nansum_arr(sz_integ[valid, j, :], sz_psd * beam.GH_weight)
+    sz_integ = np.nansum(sz_integ, axis=1)
+    sz_integ[sz_integ == 0] = np.nan
+    return sz_integ
+
+
+def combined_mask(list_beams, len_beams):
+    """scatter/scattering_sz.py:144-151."""
+    mask = np.zeros(len_beams,)
+    for beam in list_beams:
+        mask = sum_arr(mask, beam.mask[0:len_beams], cst=1)
+    mask /= len(list_beams)
+    mask[np.logical_and(mask >= 0, mask < 1)] = 0
+    return mask
+
+
+def get_radar_observables(list_beams, luts, cfg):
+    """scatter/scattering_sz.py:17-161.  Mutates its inputs like the reference
+    (truncation :56-57, elevation folding :61-68)."""
+    consts = radar_constants(cfg)
+    res = cfg['radar']['radial_resolution']
+    idx_0 = int(len(list_beams) / 2)
+    len_beams = len(list_beams[idx_0].dist_profile)
+    sz_integ = integrate_sz(list_beams, luts, cfg)
+    ZH, ZV, ZDR, RHOHV, KDP, AH, AV, DELTA_HV = get_pol_from_sz(sz_integ, consts['WAVELENGTH'])
+    KDP_m = KDP + DELTA_HV
+    PHIDP = nan_cumsum(2 * KDP_m) * res / 1000.
+    if cfg['attenuation']['correction']:
+        ZV *= nan_cumprod(10 ** (-0.1 * AV * (res / 1000.)))
+        ZH *= nan_cumprod(10 ** (-0.1 * AH * (res / 1000.)))
+        ZDR = ZH / ZV
+    obs = {'ZH': ZH, 'ZDR': ZDR, 'ZV': ZV, 'KDP': KDP_m, 'DELTA_HV': DELTA_HV,
+           'PHIDP': PHIDP, 'RHOHV': RHOHV, 'AH': AH, 'AV': AV}
+    mask = combined_mask(list_beams, len_beams)
+    c = list_beams[idx_0]
+    return Beam(obs, mask, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)
+
+
+# ----------------------------------------------------------------------------
+# refraction and quadrature
+# ----------------------------------------------------------------------------
+def get_earth_radius(latitude):
+    """refraction/atm_refraction.py:18-21."""
+    a = 6378.1370 * 1000
+    b = 6356.7523 * 1000
+    return np.sqrt(((a ** 2 * np.cos(latitude)) ** 2 + (b ** 2 * np.sin(latitude)) ** 2) /
+                   ((a * np.cos(latitude)) ** 2 + (b * np.sin(latitude)) ** 2))
+
+
+def ref_4_3(range_vec, elevation_angle, coords_radar):
+    """refraction/atm_refraction.py:110-123 (incl. the radius-at-longitude quirk :114)."""
+    el = elevation_angle * np.pi / 180.
+    ke = 4. / 3.
+    alt = coords_radar[2]
+    RE = get_earth_radius(coords_radar[1])
+    H = np.sqrt(range_vec ** 2 + (ke * RE) ** 2 + 2 * range_vec * ke * RE * np.sin(el)) - ke * RE + alt
+    S = ke * RE * np.arcsin((range_vec * np.cos(el)) / (ke * RE + H))
+    E = el + np.arctan(range_vec * np.cos(el) / (range_vec * np.sin(el) + ke * RE + alt))
+    return S.astype('float32'), H.astype('float32'), E.astype('float32') * (180.0 / np.pi)
+
+
+def radar_ranges(cfg):
+    r = cfg['radar']
+    return np.arange(r['radial_resolution'] / 2, r['range'], r['radial_resolution'])
+
+
+def gh_quadrature(cfg):
+    """interpolation/interpolation.py:67-85,226-236,260-266 (scheme 1): returns the
+    list of kept sub-beams as (ih, jv, az_offset, el_offset, weight) in reference order,
+    plus pts_ver (all vertical nodes)."""
+    bw = cfg['radar']['3dB_beamwidth']
+    nh = int(cfg['integration']['nh_GH'])
+    nv = int(cfg['integration']['nv_GH'])
+    sigma = bw / (2 * np.sqrt(2 * np.log(2)))
+    pts_hor, w_hor = np.polynomial.hermite.hermgauss(nh)
+    pts_hor = pts_hor * sigma
+    pts_ver, w_ver = np.polynomial.hermite.hermgauss(nv)
+    pts_ver = pts_ver * sigma
+    weights = np.outer(w_hor * sigma, w_ver * sigma)
+    weights *= np.abs(np.cos(pts_ver))
+    sum_weights = np.sum(weights.ravel())
+    broad = nh > 1 or nv > 1
+    ws = np.sort(np.array(weights).ravel())[::-1]
+    wc = np.cumsum(ws / sum_weights)
+    wc[-1] = 1.
+    idx = np.where(wc >= cfg['integration']['weight_threshold'])[0][0]
+    thr = ws[idx]
+    sum_weights = np.sum(ws[ws >= thr])
+    out = []
+    for i in range(nh):
+        for j in range(nv):
+            if weights[i, j] >= thr or not broad:
+                out.append((i, j, pts_hor[i], pts_ver[j], weights[i, j] / sum_weights))
+    return out, pts_ver
+
+
+# ----------------------------------------------------------------------------
+# Doppler  (doppler/doppler_sz.py)
+# ----------------------------------------------------------------------------
+DEG2RAD = np.pi / 180.0
+
+
+def proj_vel(U, V, W, VH, theta, phi):
+    """doppler/doppler_sz.py:23-24."""
+    return (U * np.sin(phi) + V * np.cos(phi)) * np.cos(theta) + (W - VH) * np.sin(theta)
+
+
+def _doppler_hydros(cfg):
+    # doppler_sz.py:55-57 passes the *integer* scheme -> 1-moment classes (hail stays 2-mom)
+    types = hydrom_types(cfg['microphysics']['scheme'])
+    return {h: Hydro(h, cfg['microphysics']['scheme']) for h in types}
+
+
+def _set_psd_doppler(hyd, h, beam, scheme, sel=None):
+    v = beam.values
+    g = (lambda a: a) if sel is None else (lambda a: a[sel])
+    if scheme == 1:
+        if h == 'S':
+            hyd.set_psd(g(v['T']), g(v['Q' + h + '_v']))
+        else:
+            hyd.set_psd(g(v['Q' + h + '_v']))
+    else:
+        hyd.set_psd(g(v['QN' + h + '_v']), g(v['Q' + h + '_v']))
+
+
+def get_v_hydro_unweighted(beam, hydros, cfg):
+    """doppler/doppler_sz.py:130-153."""
+    vh_avg = np.full(beam.values['T'].shape, np.nan)
+    n_avg = np.full(beam.values['T'].shape, np.nan)
+    for h in hydros.keys():
+        _set_psd_doppler(hydros[h], h, beam, cfg['microphysics']['scheme'])
+        vh, n = hydros[h].integrate_V()
+        vh_avg = nansum_arr(vh_avg, vh)
+        n_avg = nansum_arr(n_avg, n)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        v = vh_avg / n_avg
+    return v * (beam.values['RHO'] / beam.values['RHO'][0]) ** (0.5)
+
+
+def get_v_hydro_weighted(beam, hydros, luts, cfg):
+    """doppler/doppler_sz.py:155-231."""
+    scheme = cfg['microphysics']['scheme']
+    vh_avg = np.full(beam.values['T'].shape, np.nan)
+    n_avg = np.full(beam.values['T'].shape, np.nan)
+    for h in hydros.keys():
+        lut = luts[h]
+        list_D = lut.axes[lut.axes_names['d']]
+        valid = beam.values['Q' + h + '_v'] > 0
+        elev_lut = fold_elevation(copy.deepcopy(beam.elev_profile))
+        T = beam.values['T']
+        sz = lut.lookup_line(e=elev_lut[valid], t=T[valid])
+        rcs = 2 * np.pi * (sz[:, :, 0] - sz[:, :, 1] - sz[:, :, 2] + sz[:, :, 3])
+        rcs = rcs.T
+        _set_psd_doppler(hydros[h], h, beam, scheme, valid)
+        N = hydros[h].get_N(list_D)
+        if len(N.shape) == 1:
+            N = np.reshape(N, [len(N), 1])
+        v_f = hydros[h].get_V(list_D)
+        vh_w = np.trapz(N * v_f[:, np.newaxis] * rcs, axis=0)
+        n_w = np.trapz(N * rcs, axis=0)
+        vh_avg[valid] = nansum_arr(vh_avg[valid], vh_w)
+        n_avg[valid] = nansum_arr(n_avg[valid], n_w)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        v = vh_avg / n_avg
+    return v * (beam.values['RHO'] / beam.values['RHO'][0]) ** (0.5)
+
+
+def get_diameter_from_rad_vel(hydros, phi, theta, U, V, W, rho_corr, varray):
+    """doppler/doppler_sz.py:337-367 (incl. the all-column clipping :355-357)."""
+    theta = theta * DEG2RAD
+    phi = phi * DEG2RAD
+    wh = 1. / rho_corr * (W + (U * np.sin(phi) + V * np.cos(phi)) / np.tan(theta) - varray / np.sin(theta))
+    idx = np.where(wh >= 0)[0]
+    wh = wh[idx]
+    keys = list(hydros.keys())
+    D = np.zeros((len(idx), len(keys)), dtype='float32')
+    for i, h in enumerate(keys):
+        D[:, i] = hydros[h].get_D_from_V(wh)
+        D[D >= hydros[h].d_max] = hydros[h].d_max
+        D[D <= hydros[h].d_min] = hydros[h].d_min
+    Da = np.minimum(D[0:-1, :], D[1:, :])
+    Db = np.maximum(D[0:-1, :], D[1:, :])
+    mask = np.where(np.sum((Db - Da) == 0.0, axis=1) < len(keys))[0]
+    return Da[mask, :], Db[mask, :], idx[mask]
+
+
+def get_refl_np(n, Da, Db, D, rcs, N0, mu, lam, nu, step_D, Dmin):
+    """doppler/doppler_c.c:11-33 restated with numpy scalars: float accumulation of
+    double-precision terms, truncating index conversion, 3 classes hard-wired."""
+    refl = np.zeros(n, dtype=np.float32)
+    f32 = np.float32
+    for i in range(Da.shape[0]):
+        for j in range(3):
+            if lam[j] > 0:
+                s = f32(0)
+                ia = int(np.trunc(f32(f32(Da[i, j] - Dmin[j]) / step_D[j])))
+                ib = int(np.trunc(f32(f32(Db[i, j] - Dmin[j]) / step_D[j])))
+                for k in range(ia, ib):
+                    d = float(D[k, j])
+                    term = math.pow(d, float(mu[j])) * math.exp(-float(lam[j]) * math.pow(d, float(nu[j]))) * float(rcs[k, j])
+                    s = f32(float(s) + term)
+                refl[i] = f32(float(refl[i]) + float(f32(f32(s * step_D[j]) * N0[j])))
+    return refl
+
+
+def get_doppler_spectrum(beam, hydros, luts, cfg, consts, get_refl=get_refl_np):
+    """doppler/doppler_sz.py:233-306."""
+    scheme = cfg['microphysics']['scheme']
+    varray = consts['VARRAY']
+    len_beam = len(beam.dist_profile)
+    keys = list(hydros.keys())
+    refl = np.zeros((len_beam, len(varray)), dtype='float32')
+    D = np.column_stack([luts[h].axes[luts[h].axes_names['d']] for h in keys])
+    D_min = [hydros[h].d_min for h in keys]
+    step_D = D[1, :] - D[0, :]
+    elev = beam.elev_profile
+    elev_lut = fold_elevation(copy.deepcopy(elev))
+    phi = beam.GH_pt[0]
+    rho_corr = (beam.values['RHO'] / beam.values['RHO'][0]) ** 0.5
+    rcs = np.zeros(D.shape, dtype='float32')
+    rcs.fill(np.nan)
+    for i in range(len_beam):
+        if beam.mask[i] == 0:
+            for j, h in enumerate(keys):
+                v = beam.values
+                if scheme == 1:
+                    if h == 'S':
+                        hydros['S'].set_psd(v['T'][i], v['Q' + h + '_v'][i])
+                    else:
+                        hydros[h].set_psd(v['Q' + h + '_v'][i])
+                else:
+                    hydros[h].set_psd(v['QN' + h + '_v'][i], v['Q' + h + '_v'][i])
+            N0 = np.array([hydros[h].N0 for h in keys], dtype='float32')
+            lambdas = np.array([hydros[h].lambda_ for h in keys], dtype='float32')
+            mu = np.array([hydros[h].mu for h in keys], dtype='float32')
+            nu = np.array([hydros[h].nu for h in keys], dtype='float32')
+            for j, h in enumerate(keys):
+                sz = luts[h].lookup_line(e=elev_lut[i], t=beam.values['T'][i])
+                rcs[:, j] = (2 * np.pi * (sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3])).T
+            Da, Db, idx = get_diameter_from_rad_vel(hydros, phi, elev[i], beam.values['U'][i],
+                                                   beam.values['V'][i], beam.values['W'][i],
+                                                   rho_corr[i], varray)
+            refl[i, idx] = get_refl(len(idx), Da, Db, D, rcs, N0, mu, lambdas, nu,
+                                    step_D, np.asarray(D_min, dtype='float32'))
+            refl[i, idx] *= consts['WAVELENGTH'] ** 4 / (np.pi ** 5 * KW ** 2)
+    return refl
+
+
+def get_doppler_velocity(list_beams, luts, cfg, get_refl=get_refl_np):
+    """doppler/doppler_sz.py:26-128 (schemes 1, 2, 3)."""
+    dscheme = cfg['doppler']['scheme']
+    consts = radar_constants(cfg)
+    num_beams = len(list_beams)
+    len_beams = max([len(l.dist_profile) for l in list_beams])
+    hydros = _doppler_hydros(cfg)
+    spectrum = None
+    if dscheme in (1, 2):
+        rvel = np.zeros(len_beams,) * float('nan')
+        sum_w = np.zeros(len_beams,)
+        for beam in list_beams:
+            if dscheme == 1:
+                v_h = get_v_hydro_unweighted(beam, hydros, cfg)
+            else:
+                v_h = get_v_hydro_weighted(beam, hydros, luts, cfg)
+            theta = beam.elev_profile * DEG2RAD
+            phi = beam.GH_pt[0] * DEG2RAD
+            pw = proj_vel(beam.values['U'], beam.values['V'], beam.values['W'], v_h, theta, phi)
+            sum_w = sum_arr(sum_w, ~np.isnan(pw) * beam.GH_weight)
+            rvel = nansum_arr(rvel, pw * beam.GH_weight)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            rvel /= sum_w
+    else:
+        spectrum = np.zeros((len_beams, len(consts['VARRAY'])))
+        for beam in list_beams:
+            spectrum += get_doppler_spectrum(beam, hydros, luts, cfg, consts, get_refl) * beam.GH_weight
+        with np.errstate(invalid='ignore', divide='ignore'):
+            rvel = np.sum(np.tile(consts['VARRAY'], (len_beams, 1)) * spectrum, axis=1) / np.sum(spectrum, axis=1)
+    mask = np.zeros(len_beams,)
+    for beam in list_beams:
+        mask = sum_arr(mask, beam.mask)
+    mask /= num_beams
+    mask[np.logical_and(mask >= 0, mask < 1)] = 0
+    c = list_beams[int(num_beams / 2)]
+    vals = {'RVEL': rvel}
+    if spectrum is not None:
+        vals['DSPECTRUM'] = spectrum
+    return Beam(vals, mask, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)
+
+
+# ----------------------------------------------------------------------------
+# sensitivity cut  (utilities/utilities.py:68-105)
+# ----------------------------------------------------------------------------
+def cut_at_sensitivity(beams, cfg):
+    sens = cfg['radar']['sensitivity']
+    if not isinstance(sens, list):
+        sens = [sens]
+    if len(sens) == 2:
+        thr = lambda r: (sens[0] - 20 * np.log10(sens[1] / 1000.)) + 20 * np.log10(r / 1000.)
+    elif len(sens) == 1:
+        thr = lambda r: sens[0]
+    else:
+        return beams
+    for b in beams:
+        rr = cfg['radar']['radial_resolution'] * np.arange(len(b.dist_profile))
+        with np.errstate(invalid='ignore', divide='ignore'):
+            m = 10 * np.log10(b.values['ZH']) < thr(rr)
+        for k in b.values.keys():
+            if k in SIMULATED_VARIABLES:
+                b.values[k][m] = np.nan
+    return beams
+
+
+# ----------------------------------------------------------------------------
+# geolocation + interpolation through the C restatement (oracle_c.c)
+# ----------------------------------------------------------------------------
+_clib = None
+
+
+def clib():
+    """Load oracle/liboracle_c.so (built by `make -C oracle oracle`)."""
+    global _clib
+    if _clib is None:
+        import ctypes
+        import os
+        here = os.path.dirname(os.path.abspath(__file__))
+        lib = ctypes.CDLL(os.path.join(here, 'liboracle_c.so'))
+        dp = ctypes.POINTER(ctypes.c_double)
+        fp = ctypes.POINTER(ctypes.c_float)
+        i = ctypes.c_int
+        lib.orc_geod_fwd.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, dp, i, dp, dp]
+        lib.orc_rotpole.argtypes = [dp, dp, i, ctypes.c_double, ctypes.c_double, dp, dp]
+        lib.orc_interp.argtypes = [fp, i, fp, fp, fp, fp, i, i, i, fp, fp]
+        lib.orc_get_refl.argtypes = [fp, i, fp, i, fp, fp, i, fp, fp, fp, fp, fp, fp, fp]
+        _clib = lib
+    return _clib
+
+
+def _dp(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _fp(a):
+    import ctypes
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def geod_fwd(lon0, lat0, az, dist):
+    """WGS84 direct geodesic, one start point / azimuth, many distances
+    (restates pyproj Geod(ellps='WGS84').fwd as called at interpolation.py:322-325)."""
+    d = np.ascontiguousarray(dist, dtype=np.float64)
+    lon = np.empty_like(d)
+    lat = np.empty_like(d)
+    clib().orc_geod_fwd(float(lon0), float(lat0), float(az), _dp(d), d.size, _dp(lon), _dp(lat))
+    return lon, lat
+
+
+def wgs_to_rotated(lats, lons, pole_lat_s, pole_lon_s):
+    """Rotated-pole transform standing in for pycosmo.WGS_to_COSMO (PARITY UNPINNED).
+    Returns [n,2] = (rlat, rlon) as the call site interpolation.py:355-362 expects."""
+    la = np.ascontiguousarray(lats, dtype=np.float64)
+    lo = np.ascontiguousarray(lons, dtype=np.float64)
+    rla = np.empty_like(la)
+    rlo = np.empty_like(lo)
+    clib().orc_rotpole(_dp(la), _dp(lo), la.size, float(pole_lat_s), float(pole_lon_s), _dp(rla), _dp(rlo))
+    return np.column_stack((rla, rlo))
+
+
+def interp_c(coords, heights, data, zlev, llc, res):
+    """interpolation/interpolation_c.c:12-104 through the per-gate C restatement."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    heights = np.ascontiguousarray(heights, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    zlev = np.ascontiguousarray(zlev, dtype=np.float32)
+    llc = np.ascontiguousarray(llc, dtype=np.float32)
+    res = np.ascontiguousarray(res, dtype=np.float32)
+    out = np.empty(len(heights), dtype=np.float32)
+    nz, ny, nx = data.shape
+    clib().orc_interp(_fp(out), len(heights), _fp(coords), _fp(heights), _fp(data), _fp(zlev),
+                      nz, ny, nx, _fp(llc), _fp(res))
+    return out
+
+
+def get_refl_c(n, Da, Db, D, rcs, N0, mu, lam, nu, step_D, Dmin):
+    """doppler/doppler_c.c:11-33 through the C restatement."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    Da, Db, D, rcs, N0, mu, lam, nu, step_D, Dmin = map(f, (Da, Db, D, rcs, N0, mu, lam, nu, step_D, Dmin))
+    out = np.zeros(int(n), dtype=np.float32)
+    clib().orc_get_refl(_fp(out), int(n), _fp(Da), Da.shape[0], _fp(Db), _fp(D), D.shape[0], _fp(rcs),
+                        _fp(N0), _fp(mu), _fp(lam), _fp(nu), _fp(step_D), _fp(Dmin))
+    return out
+
+
+class ModelVar(object):
+    """Stand-in for a pycosmo variable: .data [nz,ny,nx] f32 + attributes (radar_operator.py:138)."""
+
+    def __init__(self, data, attributes):
+        self.data = data
+        self.attributes = attributes
+
+
+def get_radar_beam_trilin(list_vars, azimuth, dist, heights, cfg):
+    """interpolation/interpolation.py:311-374."""
+    radar_pos = cfg['radar']['coords']
+    lons, lats = geod_fwd(radar_pos[1], radar_pos[0], azimuth, np.asarray(dist, dtype=np.float64))
+    v0 = list_vars[0]
+    zlev = v0.attributes['z-levels']
+    proj = v0.attributes['proj_info']
+    llc = np.asarray((float(proj['Lo1']), float(proj['La1']))).astype('float32')
+    urc = np.asarray((float(proj['Lo2']), float(proj['La2']))).astype('float32')
+    res = v0.attributes['resolution']
+    coords = wgs_to_rotated(lats, lons, proj['Latitude_of_southern_pole'], proj['Longitude_of_southern_pole'])
+    if np.any(coords[:, 1] < llc[0]) or np.any(coords[:, 0] < llc[1]) or \
+            np.any(coords[:, 1] > urc[0]) or np.any(coords[:, 0] > urc[1]):
+        raise IndexError('ERROR: RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN: ABORTING')
+    beams = [interp_c(coords, heights, var.data, zlev, llc, res) for var in list_vars]
+    return lats, lons, beams
+
+
+def get_profiles_GH(dic_variables, azimuth, elevation, cfg):
+    """interpolation/interpolation.py:53-308, integration scheme 1, refraction scheme 1."""
+    keys = list(dic_variables.keys())
+    list_vars = list(dic_variables.values())
+    subs, pts_ver = gh_quadrature(cfg)
+    rr = radar_ranges(cfg)
+    refr = [ref_4_3(rr, pt + elevation, cfg['radar']['coords']) for pt in pts_ver]
+    out = []
+    for (i, j, ph, pv, w) in subs:
+        S, H, E = refr[j]
+        lats, lons, b = get_radar_beam_trilin(list_vars, ph + azimuth, S, H, cfg)
+        dic = {}
+        for k, bi in enumerate(b):
+            if k == 0:
+                mask = np.zeros((len(bi)))
+                mask[bi == -9999] = -1
+                mask[np.isnan(bi)] = 1
+            bi[mask != 0] = float('nan')
+            dic[keys[k]] = bi
+        out.append(Beam(dic, mask, lats, lons, S, H, E.copy(), [ph + azimuth, pv + elevation], w))
+    return out

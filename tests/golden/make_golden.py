@@ -1,0 +1,292 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+The Python reference is imported from /root/reference through oracle/ref_shim.py and
+its two C files are used through the gcc builds in oracle/_ref (make -C oracle ref).
+This script contains no reference source; it only calls reference functions on the
+deterministic synthetic inputs of cosmo_pol_amd/synthetic.py and stores inputs and
+outputs.  The lookup tables are not stored (they are regenerated from the same
+deterministic formula); everything else a test needs is in the .npz.
+
+    make -C oracle ref && python tests/golden/make_golden.py
+"""
+import copy
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim                      # noqa: E402
+from cosmo_pol_amd import synthetic as syn       # noqa: E402
+
+LUT_NE, LUT_NT = 8, 12      # reduced e / t axes keep the regenerated tables small
+
+
+def ref_luts(scheme, frequency):
+    from cosmo_pol.lookup.lut import Lookup_table
+    out = {}
+    for h in syn.hydrom_types(scheme):
+        e, t, d, tab = syn.synthetic_lut(h, frequency, n_e=LUT_NE, n_t=LUT_NT)
+        lut = Lookup_table()
+        lut.add_axis('e', e)
+        lut.add_axis('t', t)
+        lut.add_axis('d', d)
+        lut.add_axis('sz', np.arange(12))
+        lut.set_value_table(tab)
+        out[h] = lut
+    return out
+
+
+def ref_beams(beams):
+    from cosmo_pol.utilities.beam import Beam
+    out = []
+    for b in beams:
+        lat = np.linspace(46, 46.5, len(b['dist']))
+        out.append(Beam(copy.deepcopy(b['values']), b['mask'].copy(), lat, lat + 1, b['dist'].copy(),
+                        b['heights'].copy(), b['elev'].copy(), list(b['GH_pt']), b['GH_weight']))
+    return out
+
+
+def pack_beams(beams, prefix='in_'):
+    d = {}
+    for k in beams[0]['values']:
+        d[prefix + 'val_' + k] = np.stack([b['values'][k] for b in beams])
+    for k in ('mask', 'elev', 'dist', 'heights'):
+        d[prefix + k] = np.stack([b[k] for b in beams])
+    d[prefix + 'GH_pt'] = np.array([b['GH_pt'] for b in beams], dtype=np.float64)
+    d[prefix + 'GH_weight'] = np.array([b['GH_weight'] for b in beams], dtype=np.float64)
+    return d
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('wrote %-28s %7.1f kB' % (name + '.npz', os.path.getsize(path) / 1e3))
+
+
+def gen_psd():
+    ref_shim.install()
+    from cosmo_pol.hydrometeors import hydrometeors as H
+    rng = np.random.default_rng(3)
+    n = 48
+    q = (10 ** rng.uniform(-8, -2, n)).astype('float32')
+    q[::7] = 0
+    qn = (10 ** rng.uniform(0, 8, n)).astype('float32')
+    qn[5::11] = 0
+    t = rng.uniform(200, 310, n).astype('float32')
+    out = {'q': q, 'qn': qn, 't': t}
+    for h, sch in [('R', '1mom'), ('S', '1mom'), ('G', '1mom'), ('R', '2mom'), ('S', '2mom'), ('G', '2mom'), ('H', '2mom')]:
+        hyd = H.create_hydrometeor(h, sch)
+        d = np.linspace(hyd.d_min, hyd.d_max, 1024).astype('float32')
+        if sch == '2mom':
+            hyd.set_psd(qn, q)
+        elif h == 'S':
+            hyd.set_psd(t, q)
+        else:
+            hyd.set_psd(q)
+        with np.errstate(all='ignore'):
+            N = hyd.get_N(d)
+            v_int, n_int = hyd.integrate_V()
+        tag = h + sch[0]
+        out['lambda_' + tag] = np.asarray(hyd.lambda_, dtype=np.float64)
+        out['N0_' + tag] = np.broadcast_to(np.asarray(hyd.N0, dtype=np.float64), q.shape).copy()
+        out['N_' + tag] = np.asarray(N[::64], dtype=np.float64)
+        out['vint_' + tag] = np.asarray(v_int, dtype=np.float64)
+        out['nint_' + tag] = np.broadcast_to(np.asarray(n_int, dtype=np.float64), q.shape).copy()
+        out['consts_' + tag] = np.array([hyd.a, hyd.b, hyd.alpha, hyd.beta, hyd.mu, hyd.nu,
+                                         hyd.lambda_factor, hyd.vel_factor, hyd.ntot_factor], dtype=np.float64)
+    # known answer quoted in hydrometeors/hydrometeors.py:567
+    r = H.create_hydrometeor('R', '1mom')
+    r.set_psd(np.array([1e-3, 1e-4]))
+    out['known_lambda_R'] = np.asarray(r.lambda_)
+    save('psd', **out)
+
+
+def gen_lookup():
+    ref_shim.install()
+    luts = ref_luts(1, 5.6)
+    e = np.array([-3, 0, 0.999, 1, 1.0001, 3, 5, 6.5, 7, 13, 13.9, 14, 15, 90, 2.9999999], dtype='float32')
+    out = {'e': e}
+    for h in ('R', 'S'):
+        lo = luts[h].axes_limits[1][0]
+        t = (lo + np.array([-5, 0, 0.5, 1, 1.0000001, 3, 5, 7, 9, 9.5, 21, 22, 23, 40, 2.5], dtype='float32')).astype('float32')
+        sl = luts[h].lookup_line(e=e, t=t)
+        out['t_' + h] = t
+        out['line_' + h] = sl[:, ::128, :].copy()
+    save('lookup', **out)
+
+
+def run_observables(scheme, n_gates, n_sub, att, freq, res, seed, nan_tail, below_head):
+    cfg, constants = ref_shim.install({'microphysics': {'scheme': scheme},
+                                       'attenuation': {'correction': att},
+                                       'radar': {'frequency': freq, 'radial_resolution': res}})
+    from cosmo_pol.scatter import scattering_sz
+    beams = syn.synthetic_beams(n_gates, n_sub, scheme, seed=seed, res=res, nan_tail=nan_tail,
+                                below_head=below_head)
+    luts = ref_luts(scheme, freq)
+    with np.errstate(all='ignore'):
+        out = scattering_sz.get_radar_observables(ref_beams(beams), luts)
+    d = pack_beams(beams)
+    for k, v in out.values.items():
+        d['out_' + k] = np.asarray(v)
+    d['out_mask'] = np.asarray(out.mask)
+    d['meta'] = np.array([scheme, n_gates, n_sub, att, freq, res, seed], dtype=np.float64)
+    return d
+
+
+def gen_observables():
+    save('obs_1mom_b1', **run_observables(1, 96, 1, 1, 5.6, 75., 11, 9, 0))
+    save('obs_1mom_b9', **run_observables(1, 64, 9, 0, 9.41, 500., 12, 6, 3))
+    save('obs_2mom_b9', **run_observables(2, 80, 9, 1, 5.6, 500., 13, 8, 2))
+    save('obs_2mom_b3_x', **run_observables(2, 48, 3, 1, 9.41, 300., 14, 0, 0))
+
+
+def gen_pol():
+    cfg, constants = ref_shim.install({'radar': {'frequency': 9.41}})
+    from cosmo_pol.scatter import scattering_sz
+    rng = np.random.default_rng(5)
+    sz = np.abs(rng.standard_normal((64, 12))).astype('float32')
+    sz[:, 1:3] *= -0.1
+    sz[:, 5:7] *= 0.05
+    sz[3] = np.nan
+    with np.errstate(all='ignore'):
+        outs = scattering_sz.get_pol_from_sz(sz)
+    save('pol_from_sz', sz=sz, **{n: np.asarray(o) for n, o in
+                                 zip(['ZH', 'ZV', 'ZDR', 'RHOHV', 'KDP', 'AH', 'AV', 'DELTA_HV'], outs)},
+         wavelength=np.array(constants.WAVELENGTH))
+
+
+def gen_doppler():
+    for ds in (1, 2, 3):
+        cfg, constants = ref_shim.install({'microphysics': {'scheme': 1}, 'doppler': {'scheme': ds},
+                                           'radar': {'frequency': 9.41, 'radial_resolution': 75.,
+                                                     'PRI': 700, 'FFT_length': 256}})
+        from cosmo_pol.doppler import doppler_sz
+        beams = syn.synthetic_beams(32, 3, 1, seed=21 + ds, res=75., elevation=8.0, nan_tail=3)
+        luts = ref_luts(1, 9.41)
+        with np.errstate(all='ignore'):
+            out = doppler_sz.get_doppler_velocity(ref_beams(beams), luts)
+        d = pack_beams(beams)
+        d['out_RVEL'] = np.asarray(out.values['RVEL'])
+        if 'DSPECTRUM' in out.values:
+            d['out_DSPECTRUM'] = np.asarray(out.values['DSPECTRUM'])
+            d['varray'] = np.asarray(constants.VARRAY)
+        d['out_mask'] = np.asarray(out.mask)
+        save('doppler_s%d' % ds, **d)
+
+
+def gen_refraction():
+    ref_shim.install()
+    from cosmo_pol.refraction import atm_refraction
+    coords = [46.04079, 8.83321, 1604]
+    out = {'coords': np.array(coords)}
+    for tag, rr in (('lema', np.arange(250., 150000., 500.)), ('mxpol', np.arange(37.5, 50000., 75.))):
+        out['rr_' + tag] = rr
+        for el in (-0.2, 1.0, 3.3, 20.0, 40.0, 90.0):
+            S, H, E = atm_refraction.ref_4_3(rr, el, coords)
+            out['S_%s_%g' % (tag, el)] = S
+            out['H_%s_%g' % (tag, el)] = H
+            out['E_%s_%g' % (tag, el)] = E
+    save('refraction', **out)
+
+
+def gen_interp():
+    """Reference interpolation_c.c (gcc build) on a small terrain-following grid."""
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_ref', 'libref_interp.so'))
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.get_all_radar_pts.restype = fp
+    m = syn.synthetic_model(nz=12, ny=40, nx=48, scheme=2, seed=99, llc=(-1.0, -0.8), res=(0.05, 0.04), ztop=9000.)
+    zlev = m['zlev']
+    rng = np.random.default_rng(17)
+    n = 400
+    llc = np.array([-1.0, -0.8], dtype='float32')
+    res = np.array([0.05, 0.04], dtype='float32')
+    coords = np.empty((n, 2), dtype='float32')
+    coords[:, 0] = llc[1] + res[1] * rng.uniform(0.0, 38.99, n)      # rlat
+    coords[:, 1] = llc[0] + res[0] * rng.uniform(0.0, 46.99, n)      # rlon
+    coords[:8, 0] = llc[1] + res[1] * np.arange(8)                   # exactly on grid lines
+    coords[8:16, 1] = llc[0] + res[0] * np.arange(8)
+    H = rng.uniform(100., 9500., n).astype('float32')
+    # exact level hits, lowest-layer gates, below-lowest-level-at-a-neighbour gates
+    iy = np.floor((coords[:, 0] - llc[1]) / res[1]).astype(int)
+    ix = np.floor((coords[:, 1] - llc[0]) / res[0]).astype(int)
+    for g in range(16, 60):
+        lev = rng.integers(0, 12)
+        H[g] = zlev[lev, iy[g], ix[g]]
+    for g in range(60, 120):
+        H[g] = zlev[11, iy[g], ix[g]] + rng.uniform(-30, 200)
+    out = {'coords': coords, 'H': H, 'llc': llc, 'res': res, 'seed_model': np.array([12, 40, 48, 2, 99])}
+    i = ctypes.c_int
+    p = lambda a: a.ctypes.data_as(fp)
+    for name in ('T', 'QR_v', 'U', 'QNS_v'):
+        data = np.ascontiguousarray(m['fields'][name])
+        o = np.zeros(n, dtype='float32')
+        lib.get_all_radar_pts(p(o), i(n), p(coords), i(n), i(2), p(H), i(n), p(data), i(12), i(40), i(48),
+                              p(zlev), i(12), i(40), i(48), p(llc), i(2), p(res), i(2))
+        out['out_' + name] = o
+    save('interp', **out)
+
+
+def gen_refl():
+    """Reference doppler_c.c get_refl (gcc build) on random bins."""
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', '_ref', 'libref_doppler.so'))
+    fp = ctypes.POINTER(ctypes.c_float)
+    rng = np.random.default_rng(23)
+    nb = 40
+    D = np.column_stack([np.linspace(0.2, hi, 1024).astype('float32') for hi in (8, 20, 15)]).astype('float32')
+    step = (D[1] - D[0]).astype('float32')
+    Dmin = np.array([0.2, 0.2, 0.2], dtype='float32')
+    a = rng.uniform(0.2, 7.9, (nb, 3)).astype('float32')
+    b = np.minimum(a + rng.uniform(0, 0.4, (nb, 3)), [8., 20., 15.]).astype('float32')   # clipped like doppler_sz.py:356
+    b[::5] = a[::5]
+    rcs = (1e-4 * D ** 6).astype('float32')
+    N0 = np.array([7000., 300., 4000.], dtype='float32')
+    mu = np.array([0.5, 0., 0.], dtype='float32')
+    lam = np.array([2.2, 1.1, np.nan], dtype='float32')
+    nu = np.array([1., 1., 1.], dtype='float32')
+    o = np.zeros(nb, dtype='float32')
+    i = ctypes.c_int
+    p = lambda x: x.ctypes.data_as(fp)
+    lib.get_refl(p(o), i(nb), p(a), i(nb), i(3), p(b), i(nb), i(3), p(D), i(1024), i(3), p(rcs), i(1024), i(3),
+                 p(N0), i(3), p(mu), i(3), p(lam), i(3), p(nu), i(3), p(step), i(3), p(Dmin), i(3))
+    save('get_refl', Da=a, Db=b, D=D, rcs=rcs, N0=N0, mu=mu, lam=lam, nu=nu, step=step, Dmin=Dmin, out=o)
+
+
+def gen_cut():
+    from cosmo_pol_amd import synthetic  # noqa: F401
+    out = {}
+    rng = np.random.default_rng(31)
+    zh = (10 ** rng.uniform(-3, 4, 64)).astype('float32')
+    zh[5] = np.nan
+    for tag, sens in (('scalar', -10), ('pair', [-5, 10000])):
+        cfg, constants = ref_shim.install({'radar': {'sensitivity': sens, 'radial_resolution': 500}})
+        from cosmo_pol.utilities import utilities
+        from cosmo_pol.utilities.beam import Beam
+        vals = {'ZH': zh.copy(), 'ZDR': np.ones(64, dtype='float32'), 'AH': np.ones(64, dtype='float32')}
+        b = Beam(vals, np.zeros(64), None, None, np.zeros(64), None)
+        with np.errstate(all='ignore'):
+            utilities.cut_at_sensitivity([b])
+        out['ZH_' + tag] = b.values['ZH']
+        out['ZDR_' + tag] = b.values['ZDR']
+        out['AH_' + tag] = b.values['AH']
+    save('cut', zh=zh, **out)
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1:
+        for n in sys.argv[1:]:
+            globals()['gen_' + n]()
+        sys.exit(0)
+    gen_psd()
+    gen_lookup()
+    gen_observables()
+    gen_pol()
+    gen_doppler()
+    gen_refraction()
+    gen_interp()
+    gen_refl()
+    gen_cut()
