@@ -1,0 +1,561 @@
+// C ABI of libcosmopol_hip.so (declared in include/cosmopol.h): context, uploads and
+// the orchestration of the kernels in kernels.hip.  No Python / torch types here.
+#include "common.h"
+#include <math.h>
+#include <string.h>
+#include <mutex>
+
+static int ensure(cpol_ctx *ctx, cpol_ctx::Buf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return CPOL_OK;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 8;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    bool known = false;
+    for (auto *q : ctx->bufs) known |= (q == &b);
+    if (!known) ctx->bufs.push_back(&b);
+    return CPOL_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != CPOL_OK) return rc_; } while (0)
+
+static int fail(cpol_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int cpol_create(int device, cpol_ctx **out)
+{
+    if (!out) return CPOL_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CPOL_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return CPOL_ERR_HIP;
+    cpol_ctx *ctx = new cpol_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CPOL_ERR_HIP; }
+    memset(&ctx->cfg, 0, sizeof(ctx->cfg));
+    *out = ctx;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_destroy(cpol_ctx *ctx)
+{
+    if (!ctx) return CPOL_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto *b : ctx->bufs) if (b->p) hipFree(b->p);
+    if (ctx->zcol) hipFree(ctx->zcol);
+    if (ctx->dcol) hipFree(ctx->dcol);
+    if (ctx->quad_dev) hipFree(ctx->quad_dev);
+    for (auto &l : ctx->lut) {
+        if (l.table) hipFree(l.table);
+        if (l.xq) hipFree(l.xq);
+        if (l.xmu) hipFree(l.xmu);
+        if (l.d_axis) hipFree(l.d_axis);
+    }
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CPOL_OK;
+}
+
+extern "C" const char *cpol_last_error(cpol_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" void *cpol_stream(cpol_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int cpol_synchronize(cpol_ctx *ctx)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return CPOL_OK;
+}
+
+extern "C" int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg)
+{
+    if (!ctx || !cfg) return CPOL_ERR_ARG;
+    if (cfg->n_gates <= 0 || cfg->range_res <= 0) return fail(ctx, CPOL_ERR_ARG, "n_gates and range_res must be positive");
+    if (cfg->microphysics_scheme != 1 && cfg->microphysics_scheme != 2) return fail(ctx, CPOL_ERR_ARG, "microphysics_scheme must be 1 or 2");
+    if (cfg->doppler_scheme < 0 || cfg->doppler_scheme > 1)
+        return fail(ctx, CPOL_ERR_ARG, "doppler_scheme: only 0 (off) and 1 are implemented in the batched path");
+    ctx->cfg = *cfg;
+    if (ctx->cfg.earth_radius == 0) {
+        // atm_refraction.py:18-21 evaluated at coords[1] taken as radians (:114-117)
+        double lat = cfg->radar_lon, a = 6378.1370 * 1000, b = 6356.7523 * 1000;
+        double n1 = a * a * cos(lat), n2 = b * b * sin(lat), d1 = a * cos(lat), d2 = b * sin(lat);
+        ctx->cfg.earth_radius = sqrt((n1 * n1 + n2 * n2) / (d1 * d1 + d2 * d2));
+    }
+    ctx->have_cfg = true;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, const float *const *data,
+                                 const float *zlev, int nz, int ny, int nx, const float llc[2],
+                                 const float urc[2], const float res[2], const double pole[2])
+{
+    if (!ctx || !var_ids || !data || !zlev || !llc || !urc || !res || !pole) return CPOL_ERR_ARG;
+    if (nvars < 1 || nvars > CPOL_MAX_VARS || nz < 3 || ny < 2 || nx < 2) return fail(ctx, CPOL_ERR_ARG, "bad model shape");
+    for (int i = 0; i < nvars; i++)
+        if (var_ids[i] < 0 || var_ids[i] >= CPOL_V_COUNT || !data[i]) return fail(ctx, CPOL_ERR_ARG, "bad variable id");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    long ncell = (long)ny * nx;
+    size_t nvox = (size_t)ncell * nz;
+    if (ctx->zcol) { HIPCHK(ctx, hipFree(ctx->zcol)); ctx->zcol = nullptr; }
+    if (ctx->dcol) { HIPCHK(ctx, hipFree(ctx->dcol)); ctx->dcol = nullptr; }
+    ctx->have_model = false;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->zcol, nvox * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->dcol, nvox * nvars * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_stage, nvox * sizeof(float)));
+    float *stage = (float *)ctx->b_stage.p;
+    HIPCHK(ctx, hipMemcpyAsync(stage, zlev, nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
+    launch_transpose_levels(ctx->stream, stage, ctx->zcol, nz, ncell, 1, 0);
+    for (int i = 0; i < nvars; i++) {
+        HIPCHK(ctx, hipMemcpyAsync(stage, data[i], nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
+        launch_transpose_levels(ctx->stream, stage, ctx->dcol, nz, ncell, nvars, i);
+        ctx->var_ids[i] = var_ids[i];
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nz = nz; ctx->ny = ny; ctx->nx = nx; ctx->nv = nvars;
+    for (int k = 0; k < 2; k++) { ctx->llc[k] = llc[k]; ctx->urc[k] = urc[k]; ctx->res[k] = res[k]; ctx->pole[k] = pole[k]; }
+    ctx->have_model = true;
+    return CPOL_OK;
+}
+
+static void fill_psd(PsdView &v, const cpol_psd &p)
+{
+    v.kind = p.psd_kind; v.a = p.a; v.b = p.b; v.alpha = p.alpha; v.beta = p.beta; v.mu = p.mu; v.nu = p.nu;
+    v.lambda_factor = p.lambda_factor; v.vel_factor = p.vel_factor; v.ntot_factor = p.ntot_factor;
+    v.n0_fixed = p.n0_fixed; v.x_min = p.x_min; v.x_max = p.x_max; v.q_var = p.q_var; v.qn_var = p.qn_var;
+    v.t_var = (p.t_var >= 0 && p.t_var < CPOL_V_COUNT) ? p.t_var : CPOL_V_T;
+}
+
+extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,
+                               const cpol_psd *psd_doppler)
+{
+    if (!ctx || !lut || !psd || cls < 0 || cls >= CPOL_MAX_CLASSES) return CPOL_ERR_ARG;
+    if (lut->n_d != 1024) return fail(ctx, CPOL_ERR_ARG, "lookup tables must have 1024 diameters (compute_lut_sz.py:37)");
+    if (lut->n_e < 1 || lut->n_t < 1 || !lut->table || !lut->d_axis) return fail(ctx, CPOL_ERR_ARG, "bad lookup table");
+    if (psd->psd_kind < 0 || psd->psd_kind > 2 || psd->q_var < 0 || psd->q_var >= CPOL_V_COUNT ||
+        (psd->psd_kind == 2 && (psd->qn_var < 0 || psd->qn_var >= CPOL_V_COUNT)))
+        return fail(ctx, CPOL_ERR_ARG, "bad psd descriptor");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LutDev &L = ctx->lut[cls];
+    if (L.table) hipFree(L.table);
+    if (L.xq) hipFree(L.xq);
+    if (L.xmu) hipFree(L.xmu);
+    if (L.d_axis) hipFree(L.d_axis);
+    L = LutDev();
+    size_t nt = (size_t)lut->n_e * lut->n_t * lut->n_d * CPOL_N_SZ;
+    HIPCHK(ctx, hipMalloc((void **)&L.table, nt * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&L.xq, 1024 * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&L.xmu, 1024 * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&L.d_axis, 1024 * sizeof(float)));
+    HIPCHK(ctx, hipMemcpy(L.table, lut->table, nt * sizeof(float), hipMemcpyDefault));
+    std::vector<float> dax(1024), xq(1024), xmu(1024);
+    HIPCHK(ctx, hipMemcpy(dax.data(), lut->d_axis, 1024 * sizeof(float), hipMemcpyDefault));
+    for (int d = 0; d < 1024; d++) {
+        // D^nu in the order the integrate kernel reads it: [d/16][d%4][(d/4)%4]
+        int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
+        xq[(qd * 4 + kk) * 4 + s4] = (float)pow((double)dax[d], psd->nu);
+        xmu[d] = (float)pow((double)dax[d], psd->mu);
+    }
+    HIPCHK(ctx, hipMemcpy(L.xq, xq.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(L.xmu, xmu.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(L.d_axis, dax.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
+    L.n_e = lut->n_e; L.n_t = lut->n_t; L.n_d = lut->n_d;
+    L.e_min = lut->e_min; L.e_step = lut->e_step; L.t_min = lut->t_min; L.t_step = lut->t_step;
+    L.dD = dax[1] - dax[0];
+    L.psd = *psd;
+    L.psd_dop = psd_doppler ? *psd_doppler : *psd;
+    L.present = true;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_set_quadrature(cpol_ctx *ctx, int n_sub, const double *az_off, const double *el_off,
+                                   const double *weight)
+{
+    if (!ctx || n_sub < 1 || n_sub > 4096 || !az_off || !el_off || !weight) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->az_off.assign(az_off, az_off + n_sub);
+    ctx->el_off.assign(el_off, el_off + n_sub);
+    ctx->weight.assign(weight, weight + n_sub);
+    if (ctx->quad_dev) HIPCHK(ctx, hipFree(ctx->quad_dev));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->quad_dev, 3 * n_sub * sizeof(double)));
+    std::vector<double> q(3 * n_sub);
+    for (int i = 0; i < n_sub; i++) { q[i] = az_off[i]; q[n_sub + i] = el_off[i]; q[2 * n_sub + i] = weight[i]; }
+    HIPCHK(ctx, hipMemcpy(ctx->quad_dev, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice));
+    ctx->n_sub = n_sub;
+    return CPOL_OK;
+}
+
+// ------------------------------------------------------------------------------------
+static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
+{
+    memset(&ct, 0, sizeof(ct));
+    ct.n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
+    for (int h = 0; h < ct.n_cls; h++) {
+        const LutDev &L = ctx->lut[h];
+        if (!L.present) return fail(ctx, CPOL_ERR_STATE, "a lookup table of the microphysics scheme is missing");
+        LutView &v = ct.lut[h];
+        v.table = L.table; v.xq = L.xq; v.xmu = L.xmu; v.n_e = L.n_e; v.n_t = L.n_t; v.n_d = L.n_d;
+        v.e_min = L.e_min; v.e_step = L.e_step; v.t_min = L.t_min; v.t_step = L.t_step; v.dD = L.dD;
+        fill_psd(ct.psd[h], L.psd);
+        fill_psd(ct.dop[h], L.psd_dop);
+        if (L.n_e > ct.ne_max) ct.ne_max = L.n_e;
+        if (L.n_t > ct.nt_max) ct.nt_max = L.n_t;
+    }
+    if ((long)ct.n_cls * ct.ne_max * ct.nt_max > 8192) return fail(ctx, CPOL_ERR_ARG, "more than 8192 lookup-table nodes");
+    return CPOL_OK;
+}
+
+static void build_obs_params(const cpol_ctx *ctx, int n_sub, int n_gates, int n_cls, ObsParams &op)
+{
+    const cpol_config &c = ctx->cfg;
+    double wl = c.wavelength_mm;
+    op.n_gates = n_gates; op.n_sub = n_sub; op.n_cls = n_cls;
+    op.res = (float)c.range_res;
+    op.res_km = (float)(c.range_res / 1000.);
+    op.two_pi = (float)(2 * M_PI);
+    op.zfac = (float)(wl * wl * wl * wl / (pow(M_PI, 5) * c.kw * c.kw));
+    op.kdpfac = (float)(1e-3 * (180.0 / M_PI) * wl);
+    op.two_wl = (float)(2 * wl);
+    op.afac = (float)4.343e-3;
+    op.att_corr = c.attenuation_correction;
+    op.doppler = c.doppler_scheme;
+    op.sens_mode = c.sensitivity_mode;
+    op.sens0 = c.sensitivity[0]; op.sens1 = c.sensitivity[1];
+    op.res_d = c.range_res;
+}
+
+static void build_model_view(const cpol_ctx *ctx, ModelView &mv)
+{
+    memset(&mv, 0, sizeof(mv));
+    mv.zcol = ctx->zcol; mv.dcol = ctx->dcol;
+    mv.nz = ctx->nz; mv.ny = ctx->ny; mv.nx = ctx->nx; mv.nv = ctx->nv;
+    mv.llc0 = ctx->llc[0]; mv.llc1 = ctx->llc[1]; mv.res0 = ctx->res[0]; mv.res1 = ctx->res[1];
+    mv.urc0 = ctx->urc[0]; mv.urc1 = ctx->urc[1];
+    for (int i = 0; i < ctx->nv; i++) mv.var_of_slot[i] = ctx->var_ids[i];
+}
+
+// PSD set-up -> bucket sort -> integration -> per-ray reduction for nr rays whose
+// sub-beam profiles are already on the device.
+static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G, const float *vals, long plane,
+                       const float *elev, const signed char *mask, const double *wsub, const double *phi,
+                       float *obs, long obs_plane, long ray0, double *mask_out, double *rvel_out)
+{
+    const long nu = (long)nr * B * G;
+    const long nslots = nu * ct.n_cls;
+    const int nb = ct.n_cls * ct.ne_max * ct.nt_max;
+    TRY(ensure(ctx, ctx->b_key, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
+    TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_sorted, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->b_psd, (size_t)nslots * CPOL_N_COL * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_hist, (size_t)(4 * (nb + 1)) * sizeof(int)));
+    if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
+    int *hist = (int *)ctx->b_hist.p, *offs = hist + (nb + 1), *cursor = offs + (nb + 1), *chunk_off = cursor + (nb + 1);
+    HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)(nb + 1) * sizeof(int), ctx->stream));
+    launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme,
+                (int *)ctx->b_key.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p, hist, (double *)ctx->b_vr.p);
+    launch_scan(ctx->stream, nb, hist, offs, cursor, chunk_off);
+    launch_scatter(ctx->stream, nslots, (const int *)ctx->b_key.p, cursor, (int *)ctx->b_sorted.p);
+    long max_chunks = (nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb;
+    launch_integrate(ctx->stream, ct, max_chunks, nb, offs, chunk_off, (const int *)ctx->b_sorted.p,
+                     (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
+    ObsParams op;
+    build_obs_params(ctx, B, G, ct.n_cls, op);
+    launch_observables(ctx->stream, op, nr, nu, (const int *)ctx->b_key.p, (const double *)ctx->b_coef.p,
+                       (const float *)ctx->b_psd.p, mask, wsub, (const double *)ctx->b_vr.p, obs, obs_plane, ray0,
+                       mask_out, rvel_out);
+    HIPCHK(ctx, hipGetLastError());
+    return CPOL_OK;
+}
+
+static int check_ready(cpol_ctx *ctx, bool need_model, bool need_quad)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    if (!ctx->have_cfg) return fail(ctx, CPOL_ERR_STATE, "cpol_set_config has not been called");
+    if (need_model && !ctx->have_model) return fail(ctx, CPOL_ERR_STATE, "no model uploaded");
+    if (need_quad && ctx->n_sub < 1) return fail(ctx, CPOL_ERR_STATE, "cpol_set_quadrature has not been called");
+    return CPOL_OK;
+}
+
+static void geom_params(const cpol_ctx *ctx, GeomParams &gp)
+{
+    gp.lat0 = ctx->cfg.radar_lat; gp.lon0 = ctx->cfg.radar_lon; gp.alt = ctx->cfg.radar_alt;
+    gp.res = ctx->cfg.range_res; gp.earth_radius = ctx->cfg.earth_radius;
+    gp.pole_lat_s = ctx->pole[0]; gp.pole_lon_s = ctx->pole[1];
+    gp.n_gates = ctx->cfg.n_gates; gp.n_sub = ctx->n_sub;
+}
+
+static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)
+{
+    TRY(ensure(ctx, ctx->b_S, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_H, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_E, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_lat, nu * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_lon, nu * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_coords, nu * 2 * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_line, (size_t)nrb * 28 * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_phi, (size_t)nrb * sizeof(double)));
+    return CPOL_OK;
+}
+
+extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                                 cpol_outputs *out)
+{
+    TRY(check_ready(ctx, true, true));
+    if (n_rays < 1 || !azimuth || !elevation || !out) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ClassTable ct;
+    TRY(build_class_table(ctx, ct));
+    // every variable the scheme reads must have been uploaded
+    {
+        bool have[CPOL_V_COUNT] = {false};
+        for (int i = 0; i < ctx->nv; i++) have[ctx->var_ids[i]] = true;
+        bool ok = have[CPOL_V_T];
+        for (int h = 0; h < ct.n_cls; h++) {
+            ok = ok && have[ct.psd[h].q_var] && (ct.psd[h].qn_var < 0 || have[ct.psd[h].qn_var]);
+            if (ctx->cfg.doppler_scheme) ok = ok && have[ct.dop[h].q_var] && (ct.dop[h].qn_var < 0 || have[ct.dop[h].qn_var]);
+        }
+        if (ctx->cfg.doppler_scheme) ok = ok && have[CPOL_V_U] && have[CPOL_V_V] && have[CPOL_V_W] && have[CPOL_V_RHO];
+        if (!ok) return fail(ctx, CPOL_ERR_STATE, "the uploaded model lacks a variable the configured schemes read");
+    }
+    const int B = ctx->n_sub, G = ctx->cfg.n_gates;
+    const long RG = (long)n_rays * G;
+    TRY(ensure(ctx, ctx->b_az, n_rays * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_el, n_rays * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_status, n_rays * sizeof(int)));
+    TRY(ensure(ctx, ctx->o_obs, (size_t)CPOL_N_OBS * RG * sizeof(float)));
+    TRY(ensure(ctx, ctx->o_rvel, RG * sizeof(double)));
+    TRY(ensure(ctx, ctx->o_mask, RG * sizeof(double)));
+    TRY(ensure(ctx, ctx->o_lat, RG * sizeof(double)));
+    TRY(ensure(ctx, ctx->o_lon, RG * sizeof(double)));
+    TRY(ensure(ctx, ctx->o_dist, RG * sizeof(float)));
+    TRY(ensure(ctx, ctx->o_height, RG * sizeof(float)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_status.p, 0, n_rays * sizeof(int), ctx->stream));
+
+    long per_ray = (long)B * G;
+    int rays_per_batch = (int)(ctx->max_batch_units / per_ray);
+    if (rays_per_batch < 1) rays_per_batch = 1;
+    if (rays_per_batch > n_rays) rays_per_batch = n_rays;
+    long nu_max = (long)rays_per_batch * per_ray;
+    TRY(ensure_geom(ctx, (long)rays_per_batch * B, nu_max));
+    TRY(ensure(ctx, ctx->b_vals, (size_t)CPOL_V_COUNT * nu_max * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_mask, nu_max));
+    GeomParams gp;
+    geom_params(ctx, gp);
+    ModelView mv;
+    build_model_view(ctx, mv);
+    const double *wsub = ctx->quad_dev + 2 * B;
+    for (int r0 = 0; r0 < n_rays; r0 += rays_per_batch) {
+        int nr = n_rays - r0 < rays_per_batch ? n_rays - r0 : rays_per_batch;
+        long nu = (long)nr * per_ray;
+        launch_geom(ctx->stream, gp, nr, (const double *)ctx->b_az.p + r0, (const double *)ctx->b_el.p + r0,
+                    ctx->quad_dev, (double *)ctx->b_line.p, (float *)ctx->b_S.p, (float *)ctx->b_H.p,
+                    (float *)ctx->b_E.p, (double *)ctx->b_lat.p, (double *)ctx->b_lon.p, (float *)ctx->b_coords.p,
+                    (double *)ctx->b_phi.p, mv, (int *)ctx->b_status.p + r0);
+        launch_interp(ctx->stream, mv, nu, (const float *)ctx->b_coords.p, (const float *)ctx->b_H.p,
+                      (float *)ctx->b_vals.p, nu_max, (signed char *)ctx->b_mask.p, nullptr);
+        TRY(run_physics(ctx, ct, nr, B, G, (const float *)ctx->b_vals.p, nu_max, (const float *)ctx->b_E.p,
+                        (const signed char *)ctx->b_mask.p, wsub, (const double *)ctx->b_phi.p,
+                        (float *)ctx->o_obs.p, RG, r0, (double *)ctx->o_mask.p, (double *)ctx->o_rvel.p));
+        launch_gather_central(ctx->stream, nr, B, G, (const float *)ctx->b_S.p, (const float *)ctx->b_H.p,
+                              (const double *)ctx->b_lat.p, (const double *)ctx->b_lon.p, (float *)ctx->o_dist.p,
+                              (float *)ctx->o_height.p, (double *)ctx->o_lat.p, (double *)ctx->o_lon.p, r0);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    out->obs = (float *)ctx->o_obs.p;
+    out->rvel = ctx->cfg.doppler_scheme ? (double *)ctx->o_rvel.p : nullptr;
+    out->mask = (double *)ctx->o_mask.p;
+    out->lat = (double *)ctx->o_lat.p; out->lon = (double *)ctx->o_lon.p;
+    out->dist = (float *)ctx->o_dist.p; out->height = (float *)ctx->o_height.p;
+    out->ray_status = (int *)ctx->b_status.p;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                             cpol_outputs *host)
+{
+    if (!host) return CPOL_ERR_ARG;
+    cpol_outputs d;
+    TRY(cpol_run_rays_dev(ctx, n_rays, azimuth, elevation, &d));
+    const size_t RG = (size_t)n_rays * ctx->cfg.n_gates;
+    hipStream_t s = ctx->stream;
+    if (host->obs) HIPCHK(ctx, hipMemcpyAsync(host->obs, d.obs, CPOL_N_OBS * RG * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (host->rvel && d.rvel) HIPCHK(ctx, hipMemcpyAsync(host->rvel, d.rvel, RG * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (host->mask) HIPCHK(ctx, hipMemcpyAsync(host->mask, d.mask, RG * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (host->lat) HIPCHK(ctx, hipMemcpyAsync(host->lat, d.lat, RG * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (host->lon) HIPCHK(ctx, hipMemcpyAsync(host->lon, d.lon, RG * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (host->dist) HIPCHK(ctx, hipMemcpyAsync(host->dist, d.dist, RG * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (host->height) HIPCHK(ctx, hipMemcpyAsync(host->height, d.height, RG * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (host->ray_status) HIPCHK(ctx, hipMemcpyAsync(host->ray_status, d.ray_status, n_rays * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return CPOL_OK;
+}
+
+extern "C" int cpol_geolocate(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                              float *dist, float *height, float *elev, double *lat, double *lon,
+                              float *coords_rot, int *ray_status)
+{
+    TRY(check_ready(ctx, true, true));
+    if (n_rays < 1 || !azimuth || !elevation) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int B = ctx->n_sub, G = ctx->cfg.n_gates;
+    const long nu = (long)n_rays * B * G;
+    TRY(ensure(ctx, ctx->b_az, n_rays * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_el, n_rays * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_status, n_rays * sizeof(int)));
+    TRY(ensure_geom(ctx, (long)n_rays * B, nu));
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->b_status.p, 0, n_rays * sizeof(int), s));
+    GeomParams gp;
+    geom_params(ctx, gp);
+    ModelView mv;
+    build_model_view(ctx, mv);
+    launch_geom(s, gp, n_rays, (const double *)ctx->b_az.p, (const double *)ctx->b_el.p, ctx->quad_dev,
+                (double *)ctx->b_line.p, (float *)ctx->b_S.p, (float *)ctx->b_H.p, (float *)ctx->b_E.p,
+                (double *)ctx->b_lat.p, (double *)ctx->b_lon.p, (float *)ctx->b_coords.p, (double *)ctx->b_phi.p, mv,
+                (int *)ctx->b_status.p);
+    HIPCHK(ctx, hipGetLastError());
+    if (dist) HIPCHK(ctx, hipMemcpyAsync(dist, ctx->b_S.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (height) HIPCHK(ctx, hipMemcpyAsync(height, ctx->b_H.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (elev) HIPCHK(ctx, hipMemcpyAsync(elev, ctx->b_E.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (lat) HIPCHK(ctx, hipMemcpyAsync(lat, ctx->b_lat.p, nu * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (lon) HIPCHK(ctx, hipMemcpyAsync(lon, ctx->b_lon.p, nu * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (coords_rot) HIPCHK(ctx, hipMemcpyAsync(coords_rot, ctx->b_coords.p, nu * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (ray_status) HIPCHK(ctx, hipMemcpyAsync(ray_status, ctx->b_status.p, n_rays * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return CPOL_OK;
+}
+
+extern "C" int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords_rot, const float *heights, float *out)
+{
+    if (!ctx || n < 1 || !coords_rot || !heights || !out) return CPOL_ERR_ARG;
+    if (!ctx->have_model) return fail(ctx, CPOL_ERR_STATE, "no model uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    TRY(ensure(ctx, ctx->t_a, (size_t)n * 2 * sizeof(float)));
+    TRY(ensure(ctx, ctx->t_b, (size_t)n * sizeof(float)));
+    TRY(ensure(ctx, ctx->t_c, (size_t)n * ctx->nv * sizeof(float)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->t_a.p, coords_rot, (size_t)n * 2 * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->t_b.p, heights, (size_t)n * sizeof(float), hipMemcpyDefault, s));
+    ModelView mv;
+    build_model_view(ctx, mv);
+    launch_interp(s, mv, n, (const float *)ctx->t_a.p, (const float *)ctx->t_b.p, nullptr, 0, nullptr, (float *)ctx->t_c.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->t_c.p, (size_t)n * ctx->nv * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return CPOL_OK;
+}
+
+extern "C" int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates, const float *values,
+                                           const float *elev, const double *mask, const double *weight,
+                                           const double *az_sub, float *obs, double *mask_out, double *rvel)
+{
+    TRY(check_ready(ctx, false, false));
+    if (n_sub < 1 || n_gates < 1 || !values || !elev || !mask || !weight) return CPOL_ERR_ARG;
+    if (ctx->cfg.doppler_scheme && !az_sub) return fail(ctx, CPOL_ERR_ARG, "az_sub is required with a Doppler scheme");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ClassTable ct;
+    TRY(build_class_table(ctx, ct));
+    hipStream_t s = ctx->stream;
+    const long nu = (long)n_sub * n_gates;
+    TRY(ensure(ctx, ctx->b_vals, (size_t)CPOL_V_COUNT * nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_E, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_mask, nu));
+    TRY(ensure(ctx, ctx->t_a, n_sub * sizeof(double)));
+    TRY(ensure(ctx, ctx->t_b, n_sub * sizeof(double)));
+    TRY(ensure(ctx, ctx->t_c, (size_t)CPOL_N_OBS * n_gates * sizeof(float)));
+    TRY(ensure(ctx, ctx->t_d, n_gates * sizeof(double)));
+    TRY(ensure(ctx, ctx->t_e, n_gates * sizeof(double)));
+    std::vector<signed char> m8(nu);
+    for (long i = 0; i < nu; i++) m8[i] = (signed char)(mask[i] > 0 ? 1 : (mask[i] < 0 ? -1 : 0));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_vals.p, values, (size_t)CPOL_V_COUNT * nu * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_E.p, elev, nu * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->b_mask.p, m8.data(), nu, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->t_a.p, weight, n_sub * sizeof(double), hipMemcpyDefault, s));
+    if (az_sub) HIPCHK(ctx, hipMemcpyAsync(ctx->t_b.p, az_sub, n_sub * sizeof(double), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));      // m8 is a local buffer
+    int save_sens = ctx->cfg.sensitivity_mode;
+    ctx->cfg.sensitivity_mode = 0;             // get_radar_observables itself applies no cut
+    int rc = run_physics(ctx, ct, 1, n_sub, n_gates, (const float *)ctx->b_vals.p, nu, (const float *)ctx->b_E.p,
+                         (const signed char *)ctx->b_mask.p, (const double *)ctx->t_a.p, (const double *)ctx->t_b.p,
+                         (float *)ctx->t_c.p, n_gates, 0, (double *)ctx->t_d.p, (double *)ctx->t_e.p);
+    ctx->cfg.sensitivity_mode = save_sens;
+    TRY(rc);
+    if (obs) HIPCHK(ctx, hipMemcpyAsync(obs, ctx->t_c.p, (size_t)CPOL_N_OBS * n_gates * sizeof(float), hipMemcpyDefault, s));
+    if (mask_out) HIPCHK(ctx, hipMemcpyAsync(mask_out, ctx->t_d.p, n_gates * sizeof(double), hipMemcpyDefault, s));
+    if (rvel && ctx->cfg.doppler_scheme) HIPCHK(ctx, hipMemcpyAsync(rvel, ctx->t_e.p, n_gates * sizeof(double), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return CPOL_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Drop-in symbols of the reference's two C files.
+// ------------------------------------------------------------------------------------
+static std::mutex g_mutex;
+static cpol_ctx *g_ctx = nullptr;
+
+static cpol_ctx *global_ctx()
+{
+    if (!g_ctx) cpol_create(0, &g_ctx);
+    return g_ctx;
+}
+
+extern "C" float *get_all_radar_pts(float *output, int len, float *coords_rad_pts, int crp_x, int crp_y,
+                                    float *radar_heights, int rh_x, float *model_data, int md_x, int md_y, int md_z,
+                                    float *model_heights, int mh_x, int mh_y, int mh_z,
+                                    float *llc_cosmo, int llc_cosmo_x, float *res_cosmo, int res_cosmo_x)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    cpol_ctx *ctx = global_ctx();
+    (void)len; (void)rh_x; (void)llc_cosmo_x; (void)res_cosmo_x;
+    if (!ctx || crp_y != 2 || md_x != mh_x || md_y != mh_y || md_z != mh_z) return nullptr;
+    int vid = 0;
+    const float *data[1] = {model_data};
+    float urc[2] = {llc_cosmo[0] + res_cosmo[0] * (md_z - 1), llc_cosmo[1] + res_cosmo[1] * (md_y - 1)};
+    double pole[2] = {0, 0};
+    if (cpol_upload_model(ctx, 1, &vid, data, model_heights, md_x, md_y, md_z, llc_cosmo, urc, res_cosmo, pole) != CPOL_OK)
+        return nullptr;
+    if (cpol_interp_points(ctx, crp_x, coords_rad_pts, radar_heights, output) != CPOL_OK) return nullptr;
+    return output;
+}
+
+extern "C" float *get_refl(float *refl, int len, float *Da, int len_D_bins_x, int o2, float *Db, int o3, int o4,
+                           float *D, int o5, int o6, float *rcs, int o8, int o9, float *N0, int o10,
+                           float *mu, int o11, float *lambda, int o12, float *nu, int o13,
+                           float *step_D, int o14, float *Dmin, int o15)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    cpol_ctx *ctx = global_ctx();
+    (void)o2; (void)o3; (void)o4; (void)o6; (void)o8; (void)o9; (void)o10; (void)o11; (void)o12; (void)o13; (void)o14; (void)o15;
+    if (!ctx || len < len_D_bins_x) return nullptr;
+    hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    const int nb = len_D_bins_x, nd = o5;
+    size_t fb = sizeof(float);
+    size_t total = (size_t)len + 2 * (size_t)nb * 3 + 2 * (size_t)nd * 3 + 18;
+    if (ensure(ctx, ctx->t_a, total * fb) != CPOL_OK) return nullptr;
+    float *d_refl = (float *)ctx->t_a.p, *d_Da = d_refl + len, *d_Db = d_Da + nb * 3, *d_D = d_Db + nb * 3,
+          *d_rcs = d_D + nd * 3, *d_par = d_rcs + nd * 3;
+    hipMemsetAsync(d_refl, 0, len * fb, s);
+    hipMemcpyAsync(d_Da, Da, nb * 3 * fb, hipMemcpyDefault, s);
+    hipMemcpyAsync(d_Db, Db, nb * 3 * fb, hipMemcpyDefault, s);
+    hipMemcpyAsync(d_D, D, nd * 3 * fb, hipMemcpyDefault, s);
+    hipMemcpyAsync(d_rcs, rcs, nd * 3 * fb, hipMemcpyDefault, s);
+    const float *par[6] = {N0, mu, lambda, nu, step_D, Dmin};
+    for (int i = 0; i < 6; i++) hipMemcpyAsync(d_par + 3 * i, par[i], 3 * fb, hipMemcpyDefault, s);
+    if (nb > 0)
+        launch_get_refl(s, d_refl, nb, d_Da, d_Db, d_D, d_rcs, d_par, d_par + 3, d_par + 6, d_par + 9, d_par + 12, d_par + 15);
+    hipMemcpyAsync(refl, d_refl, len * fb, hipMemcpyDefault, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    return refl;
+}

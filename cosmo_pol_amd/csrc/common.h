@@ -1,0 +1,132 @@
+// Shared declarations of the HIP implementation (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/cosmopol.h"
+
+#define CPOL_WAVE 64
+#define CPOL_CHUNK_UNITS 256      // units (gate x sub-beam x class) per integrate workgroup
+#define CPOL_N_COL 16             // MFMA N dimension: 12 scattering components + 4 spare columns
+
+struct LutDev {
+    bool   present = false;
+    int    n_e = 0, n_t = 0, n_d = 0;
+    float  e_min = 0, e_step = 1, t_min = 0, t_step = 1;
+    float  dD = 0;                 // D[1]-D[0] in float32 (scattering_sz.py:50)
+    float *table = nullptr;        // [n_e][n_t][n_d][12]
+    float *xq = nullptr;           // D^nu, permuted for the integrate kernel's ds_read_b128
+    float *xmu = nullptr;          // D^mu
+    float *d_axis = nullptr;       // [n_d]
+    cpol_psd psd, psd_dop;
+};
+
+// Kernel-side view of one class.
+struct LutView {
+    const float *table;
+    const float *xq;
+    const float *xmu;
+    int   n_e, n_t, n_d;
+    float e_min, e_step, t_min, t_step;
+    float dD;
+};
+
+struct PsdView {
+    int    kind;
+    double a, b, alpha, beta, mu, nu, lambda_factor, vel_factor, ntot_factor, n0_fixed, x_min, x_max;
+    int    q_var, qn_var, t_var;
+};
+
+struct ClassTable {
+    int     n_cls;
+    int     ne_max, nt_max;        // bucket id = (cls*ne_max + ie)*nt_max + it
+    LutView lut[CPOL_MAX_CLASSES];
+    PsdView psd[CPOL_MAX_CLASSES];
+    PsdView dop[CPOL_MAX_CLASSES];
+};
+
+struct ModelView {
+    const float *zcol;             // [ny][nx][nz]     heights, level index fastest
+    const float *dcol;             // [ny][nx][nz][nv] variables interleaved per level
+    int   nz, ny, nx, nv;
+    float llc0, llc1, res0, res1;  // (Lo1, La1), (dlon, dlat)
+    float urc0, urc1;
+    int   var_of_slot[CPOL_MAX_VARS];   // uploaded variable i -> cpol_var slot
+};
+
+struct GeomParams {
+    double lat0, lon0, alt;        // radar.coords
+    double res;                    // radial resolution
+    double earth_radius;           // get_earth_radius(coords[1]) (atm_refraction.py:114-117)
+    double pole_lat_s, pole_lon_s;
+    int    n_gates, n_sub;
+};
+
+struct ObsParams {
+    int    n_gates, n_sub, n_cls;
+    float  res, res_km;            // radial resolution and resolution / 1000 as float32 operands
+    float  two_pi, zfac, kdpfac, two_wl, afac;
+    int    att_corr, doppler, sens_mode;
+    double sens0, sens1, res_d;
+};
+
+struct cpol_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_cfg = false, have_model = false;
+    cpol_config cfg;
+    // model
+    float *zcol = nullptr, *dcol = nullptr;
+    int nz = 0, ny = 0, nx = 0, nv = 0;
+    int var_ids[CPOL_MAX_VARS];
+    float llc[2], urc[2], res[2];
+    double pole[2];
+    LutDev lut[CPOL_MAX_CLASSES];
+    // quadrature
+    int n_sub = 0;
+    std::vector<double> az_off, el_off, weight;
+    double *quad_dev = nullptr;    // [3][n_sub]: az_off, el_off, weight
+    // grow-only device workspaces
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    std::vector<Buf *> bufs;
+    Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
+        b_sorted, b_psd, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+        o_obs, o_rvel, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
+    size_t max_batch_units = (size_t)8 << 20;     // (ray x sub-beam x gate) positions per batch
+};
+
+#define HIPCHK(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return CPOL_ERR_HIP;                                                           \
+        }                                                                                  \
+    } while (0)
+
+// kernels.hip
+void launch_transpose_levels(hipStream_t s, const float *src, float *dst, int nz, long ncell, int stride, int offset);
+void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *az, const double *el,
+                 const double *quad, double *line, float *S, float *H, float *E, double *lat, double *lon,
+                 float *coords, double *phi, const ModelView &mv, int *status);
+void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coords, const float *H,
+                   float *vals, long plane, signed char *mask, float *raw_out);
+void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
+                 const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
+                 const double *phi, int doppler, int *key, float2 *lam, double *coef, int *hist, double *vr);
+void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off);
+void launch_scatter(hipStream_t s, long nslots, const int *key, int *cursor, int *sorted);
+void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
+                      const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
+void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
+                        const double *coef, const float *psd_out, const signed char *mask,
+                        const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
+                        long ray0, double *mask_out, double *rvel_out);
+void launch_gather_central(hipStream_t s, int n_rays, int n_sub, int n_gates, const float *S, const float *H,
+                           const double *lat, const double *lon, float *dist, float *height, double *olat,
+                           double *olon, long ray0);
+void launch_get_refl(hipStream_t s, float *refl, int nbins, const float *Da, const float *Db, const float *D,
+                     const float *rcs, const float *N0, const float *mu, const float *lam, const float *nu,
+                     const float *step, const float *dmin);

@@ -1,0 +1,900 @@
+// HIP kernels of the cosmo_pol hot path for gfx950 (MI355X, wave64).
+//
+// Built with -ffp-contract=off: the geometry and interpolation kernels must reproduce
+// the reference's float32 / float64 operation order (no implicit FMA); fused operations
+// are written explicitly (fmaf / MFMA) where they are wanted.
+#include "common.h"
+#include <math.h>
+
+#define DEG (M_PI / 180.0)
+
+// =============================================================================
+// model upload: [nz][ncell] -> [ncell][nz] with an output stride (variable interleave)
+// =============================================================================
+__global__ void k_transpose(const float *__restrict__ src, float *__restrict__ dst, int nz, long ncell,
+                            int stride, int offset)
+{
+    __shared__ float tile[32][33];
+    long c0 = (long)blockIdx.x * 32;
+    int k0 = blockIdx.y * 32;
+    int tx = threadIdx.x, ty = threadIdx.y;
+    for (int j = ty; j < 32; j += 8) {
+        int k = k0 + j;
+        long c = c0 + tx;
+        if (k < nz && c < ncell) tile[j][tx] = src[(long)k * ncell + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        long c = c0 + j;
+        int k = k0 + tx;
+        if (k < nz && c < ncell) dst[(c * nz + k) * stride + offset] = tile[tx][j];
+    }
+}
+
+void launch_transpose_levels(hipStream_t s, const float *src, float *dst, int nz, long ncell, int stride, int offset)
+{
+    dim3 grid((unsigned)((ncell + 31) / 32), (unsigned)((nz + 31) / 32));
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, s, src, dst, nz, ncell, stride, offset);
+}
+
+// =============================================================================
+// geometry: refraction (atm_refraction.py:110-123), WGS84 direct geodesic (what
+// pyproj Geod.fwd does at interpolation.py:322-325; Karney 2013 series, order 6),
+// rotated-pole transform (interpolation.py:355).
+// =============================================================================
+#define LINE_N 28
+
+__device__ inline double polyv(int n, const double *p, double x)
+{
+    double y = *p++;
+    while (--n >= 0) y = y * x + *p++;
+    return y;
+}
+
+__device__ inline double sin_cos_series(double sinx, double cosx, const double *c, int n)
+{   // Clenshaw sum of c[1..n] sin(2 k x); c[0] unused
+    c += (n + 1);
+    double ar = 2 * (cosx - sinx) * (cosx + sinx);
+    double y0 = (n & 1) ? *--c : 0, y1 = 0;
+    n /= 2;
+    while (n--) {
+        y1 = ar * y0 - y1 + *--c;
+        y0 = ar * y1 - y0 + *--c;
+    }
+    return 2 * sinx * cosx * y0;
+}
+
+__device__ inline double ang_round(double x)
+{
+    const double z = 1 / 16.0;
+    if (x == 0) return 0;
+    double y = fabs(x);
+    y = y < z ? z - (z - y) : y;
+    return x < 0 ? -y : y;
+}
+
+__device__ inline double ang_normalize(double x)
+{
+    x = remainder(x, 360.0);
+    return x != -180 ? x : 180;
+}
+
+__device__ inline void sincosd(double x, double *sx, double *cx)
+{
+    int q;
+    double r = remquo(x, 90.0, &q);
+    r *= DEG;
+    double s = sin(r), c = cos(r);
+    switch ((unsigned)q & 3U) {
+    case 0U: *sx = s;  *cx = c;  break;
+    case 1U: *sx = c;  *cx = -s; break;
+    case 2U: *sx = -s; *cx = -c; break;
+    default: *sx = -c; *cx = s;  break;
+    }
+    if (x != 0) { *sx += 0.0; *cx += 0.0; }
+}
+
+__device__ inline double atan2d(double y, double x)
+{
+    int q = 0;
+    if (fabs(y) > fabs(x)) { double t = x; x = y; y = t; q = 2; }
+    if (x < 0) { x = -x; ++q; }
+    double ang = atan2(y, x) / DEG;
+    switch (q) {
+    case 1: ang = (y >= 0 ? 180 : -180) - ang; break;
+    case 2: ang = 90 - ang; break;
+    case 3: ang = -90 + ang; break;
+    }
+    return ang;
+}
+
+__constant__ double c_C1[18] = {-1, 6, -16, 32, -9, 64, -128, 2048, 9, -16, 768, 3, -5, 512, -7, 1280, -7, 2048};
+__constant__ double c_C1p[18] = {205, -432, 768, 1536, 4005, -4736, 3840, 12288, -225, 116, 384,
+                                 -7173, 2695, 7680, 3467, 7680, 38081, 61440};
+__constant__ double c_A3[18] = {-3, 128, -2, -3, 64, -1, -3, -1, 16, 3, -1, -2, 8, 1, -1, 2, 1, 1};
+__constant__ double c_C3[45] = {3, 128, 2, 5, 128, -1, 3, 3, 64, -1, 0, 1, 8, -1, 1, 4, 5, 256, 1, 3, 128,
+                                -3, -2, 3, 64, 1, -3, 2, 32, 7, 512, -10, 9, 384, 5, -9, 5, 192, 7, 512,
+                                -14, 7, 512, 21, 2560};
+
+// One thread per (ray, sub-beam): constants of the geodesic line through the radar.
+__global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict__ az, const double *__restrict__ el,
+                            const double *__restrict__ quad, double *__restrict__ line, double *__restrict__ phi)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rays * gp.n_sub) return;
+    int r = t / gp.n_sub, b = t % gp.n_sub;
+    double azi1 = quad[b] + az[r];                       // pts_hor[i] + azimuth (interpolation.py:265)
+    double el_b = quad[gp.n_sub + b] + el[r];            // pts_ver[j] + elevation
+    double *L = line + (long)t * LINE_N;
+    phi[t] = azi1;
+
+    const double f = 1.0 / 298.257223563, f1 = 1 - f, e2 = f * (2 - f), ep2 = e2 / (f1 * f1);
+    const double n = f / (2 - f);
+    const double tiny = 1.4916681462400413e-154;         // sqrt(DBL_MIN)
+    double A3x[6], C3x[15], C1a[7], C1pa[7], C3a[6];
+    {
+        int o = 0, k = 0;
+        for (int j = 5; j >= 0; --j) {
+            int m = 5 - j < j ? 5 - j : j;
+            A3x[k++] = polyv(m, c_A3 + o, n) / c_A3[o + m + 1];
+            o += m + 2;
+        }
+        o = 0; k = 0;
+        for (int l = 1; l < 6; ++l)
+            for (int j = 5; j >= l; --j) {
+                int m = 5 - j < j ? 5 - j : j;
+                C3x[k++] = polyv(m, c_C3 + o, n) / c_C3[o + m + 1];
+                o += m + 2;
+            }
+    }
+    double salp1, calp1, sbet1, cbet1;
+    azi1 = ang_normalize(azi1);
+    sincosd(ang_round(azi1), &salp1, &calp1);
+    sincosd(ang_round(gp.lat0), &sbet1, &cbet1);
+    sbet1 *= f1;
+    { double h = hypot(sbet1, cbet1); sbet1 /= h; cbet1 /= h; }
+    cbet1 = cbet1 > tiny ? cbet1 : tiny;
+    double salp0 = salp1 * cbet1;
+    double calp0 = hypot(calp1, salp1 * sbet1);
+    double ssig1 = sbet1, somg1 = salp0 * sbet1;
+    double csig1 = (sbet1 != 0 || calp1 != 0) ? cbet1 * calp1 : 1;
+    double comg1 = csig1;
+    { double h = hypot(ssig1, csig1); ssig1 /= h; csig1 /= h; }
+    double k2 = calp0 * calp0 * ep2;
+    double eps = k2 / (2 * (1 + sqrt(1 + k2)) + k2);
+    double A1m1;
+    {
+        const double co[5] = {1, 4, 64, 0, 256};
+        double tt = polyv(3, co, eps * eps) / co[4];
+        A1m1 = (tt + eps) / (1 - eps);
+    }
+    {
+        double eps2 = eps * eps, d = eps;
+        int o = 0;
+        for (int l = 1; l <= 6; ++l) {
+            int m = (6 - l) / 2;
+            C1a[l] = d * polyv(m, c_C1 + o, eps2) / c_C1[o + m + 1];
+            C1pa[l] = d * polyv(m, c_C1p + o, eps2) / c_C1p[o + m + 1];
+            o += m + 2;
+            d *= eps;
+        }
+    }
+    double B11 = sin_cos_series(ssig1, csig1, C1a, 6);
+    double s = sin(B11), c = cos(B11);
+    double stau1 = ssig1 * c + csig1 * s;
+    double ctau1 = csig1 * c - ssig1 * s;
+    double A3c = -f * salp0 * polyv(5, A3x, eps);
+    {
+        double mult = 1;
+        int o = 0;
+        for (int l = 1; l < 6; ++l) {
+            int m = 6 - l - 1;
+            mult *= eps;
+            C3a[l] = mult * polyv(m, C3x + o, eps);
+            o += m + 1;
+        }
+    }
+    double B31 = sin_cos_series(ssig1, csig1, C3a, 5);
+    L[0] = salp0; L[1] = calp0; L[2] = ssig1; L[3] = csig1; L[4] = somg1; L[5] = comg1;
+    L[6] = k2; L[7] = A1m1; L[8] = B11; L[9] = stau1; L[10] = ctau1; L[11] = A3c; L[12] = B31;
+    for (int l = 1; l <= 6; ++l) L[12 + l] = C1pa[l];
+    for (int l = 1; l <= 5; ++l) L[18 + l] = C3a[l];
+    L[24] = el_b;
+}
+
+// One thread per (ray, sub-beam, gate).
+__global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict__ line,
+                           float *__restrict__ S_out, float *__restrict__ H_out, float *__restrict__ E_out,
+                           double *__restrict__ lat_out, double *__restrict__ lon_out, float *__restrict__ coords,
+                           ModelView mv, int *__restrict__ status)
+{
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_total) return;
+    int g = (int)(u % gp.n_gates);
+    long rb = u / gp.n_gates;
+    const double *L = line + rb * LINE_N;
+
+    // ---- refraction, 4/3 earth model (atm_refraction.py:110-123) ----
+    double rr = gp.res / 2 + g * gp.res;                 // np.arange(res/2, range, res)
+    double ela = L[24] * M_PI / 180.;
+    double sel = sin(ela), cel = cos(ela);
+    const double ke = 4. / 3.;
+    double keR = ke * gp.earth_radius;
+    double Hd = sqrt(rr * rr + keR * keR + 2 * rr * ke * gp.earth_radius * sel) - keR + gp.alt;
+    double Sd = keR * asin((rr * cel) / (keR + Hd));
+    double Ed = ela + atan(rr * cel / (rr * sel + keR + gp.alt));
+    float S = (float)Sd, H = (float)Hd;
+    float E = (float)Ed * (float)(180.0 / M_PI);
+    S_out[u] = S; H_out[u] = H; E_out[u] = E;
+
+    // ---- geodesic position at distance S along the line ----
+    const double f = 1.0 / 298.257223563, f1 = 1 - f;
+    const double bsemi = 6378137.0 * f1;
+    const double tiny = 1.4916681462400413e-154;
+    double salp0 = L[0], calp0 = L[1], ssig1 = L[2], csig1 = L[3], somg1 = L[4], comg1 = L[5];
+    double A1m1 = L[7], B11 = L[8], stau1 = L[9], ctau1 = L[10], A3c = L[11], B31 = L[12];
+    double C1pa[7], C3a[6];
+    for (int l = 1; l <= 6; ++l) C1pa[l] = L[12 + l];
+    for (int l = 1; l <= 5; ++l) C3a[l] = L[18 + l];
+    double tau12 = (double)S / (bsemi * (1 + A1m1));
+    double s = sin(tau12), c = cos(tau12);
+    double B12 = -sin_cos_series(stau1 * c + ctau1 * s, ctau1 * c - stau1 * s, C1pa, 6);
+    double sig12 = tau12 - (B12 - B11);
+    double ssig12 = sin(sig12), csig12 = cos(sig12);
+    double ssig2 = ssig1 * csig12 + csig1 * ssig12;
+    double csig2 = csig1 * csig12 - ssig1 * ssig12;
+    double sbet2 = calp0 * ssig2;
+    double cbet2 = hypot(salp0, calp0 * csig2);
+    if (cbet2 == 0) cbet2 = csig2 = tiny;
+    double somg2 = salp0 * ssig2, comg2 = csig2;
+    double omg12 = atan2(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);
+    double lam12 = omg12 + A3c * (sig12 + (sin_cos_series(ssig2, csig2, C3a, 5) - B31));
+    double lon12 = lam12 / DEG;
+    double lon = ang_normalize(ang_normalize(gp.lon0) + ang_normalize(lon12));
+    double lat = atan2d(sbet2, f1 * cbet2);
+    lat_out[u] = lat; lon_out[u] = lon;
+
+    // ---- rotated pole (north pole from the southern-pole metadata) ----
+    double pollat = -gp.pole_lat_s, pollon = gp.pole_lon_s - 180.0;
+    if (pollon < -180.0) pollon += 360.0;
+    double sp = sin(pollat * DEG), cp = cos(pollat * DEG);
+    double ph = lat * DEG, dl = (lon - pollon) * DEG;
+    double sphi = sin(ph), cphi = cos(ph), sdl = sin(dl), cdl = cos(dl);
+    double a0 = cp * cphi * cdl + sp * sphi;
+    double a1 = -sdl * cphi;
+    double a2 = -sp * cphi * cdl + cp * sphi;
+    double rlat = asin(a0) / DEG, rlon = atan2(a1, a2) / DEG;
+    coords[2 * u] = (float)rlat;
+    coords[2 * u + 1] = (float)rlon;
+    // domain check of interpolation.py:359-362 (float64 coordinates against float32 corners)
+    if (rlon < (double)mv.llc0 || rlat < (double)mv.llc1 || rlon > (double)mv.urc0 || rlat > (double)mv.urc1) {
+        int r = (int)(rb / gp.n_sub);
+        status[r] = CPOL_ERR_DOMAIN;
+    }
+}
+
+void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *az, const double *el,
+                 const double *quad, double *line, float *S, float *H, float *E, double *lat, double *lon,
+                 float *coords, double *phi, const ModelView &mv, int *status)
+{
+    int nl = n_rays * gp.n_sub;
+    hipLaunchKernelGGL(k_geom_line, dim3((nl + 63) / 64), dim3(64), 0, s, gp, n_rays, az, el, quad, line, phi);
+    long n_total = (long)nl * gp.n_gates;
+    hipLaunchKernelGGL(k_geom_pts, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, s, gp, n_total, line,
+                       S, H, E, lat, lon, coords, mv, status);
+}
+
+// =============================================================================
+// trilinear interpolation (interpolation_c.c:12-164), one thread per point, every
+// variable in one pass.  The level search is the reference's loop, so the chosen
+// levels are identical; the arithmetic is float32 in the reference's order.
+// =============================================================================
+__device__ inline int level_search(const float *__restrict__ col, int dim, float key)
+{   // interpolation_c.c:108-135 on a contiguous, descending column
+    int high = 0, low = dim - 1;
+    if (key > col[0]) return -1;
+    else if (key < col[dim - 1]) return -2;
+    while (high < low) {
+        int middle = (high + low) / 2;
+        float v = col[middle];
+        if (v == key) return middle;
+        else if (low == middle || high == middle) return high;
+        else if (v < key) low = middle;
+        else if (v > key) high = middle;
+        else return high;          // NaN height: the reference would not terminate
+    }
+    return high;
+}
+
+__global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords, const float *__restrict__ Hh,
+                         float *__restrict__ vals, long plane, signed char *__restrict__ mask,
+                         float *__restrict__ raw_out)
+{
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const float qnan = __builtin_nanf("");
+    float H = Hh[u];
+    float p0 = (coords[2 * u] - mv.llc1) / mv.res1;       // lat-like -> row
+    float p1 = (coords[2 * u + 1] - mv.llc0) / mv.res0;   // lon-like -> column
+    int iy = (int)floorf(p0), ix = (int)floorf(p1);
+    float x = fmodf(p0, 1.0f), y = fmodf(p1, 1.0f);
+    float dx = 1.0f - x, dy = 1.0f - y;
+    int code = 0;          // 0 ok, 1 below terrain (NaN), -1 above the domain (-9999)
+    int c1[4];
+    const int nz = mv.nz;
+    long cell[4];
+    if (iy < 0 || ix < 0 || iy + 1 >= mv.ny || ix + 1 >= mv.nx || !(p0 == p0) || !(p1 == p1)) {
+        code = 1;          // outside the grid: the reference raises before reaching the C code
+    } else {
+        cell[0] = (long)iy * mv.nx + ix; cell[1] = cell[0] + 1;
+        cell[2] = cell[0] + mv.nx;       cell[3] = cell[2] + 1;
+        float t0 = mv.zcol[cell[0] * nz + nz - 1], t1 = mv.zcol[cell[1] * nz + nz - 1];
+        float t2 = mv.zcol[cell[2] * nz + nz - 1], t3 = mv.zcol[cell[3] * nz + nz - 1];
+        float topo = dx * dy * t0 + x * t2 * dy + dx * t1 * y + x * y * t3;
+        if (!(topo < H)) code = 1;
+        else {
+            for (int j = 0; j < 4; j++) {
+                int idx = level_search(mv.zcol + cell[j] * nz, nz, H);
+                if (idx == -1) { code = -1; break; }
+                if (idx == -2) idx = nz - 3;
+                else if (idx == nz - 2) idx--;
+                c1[j] = idx;
+            }
+        }
+    }
+    if (mask) mask[u] = (signed char)code;
+    const int nv = mv.nv;
+    if (code != 0) {
+        // raw_out keeps the reference's sentinels; vals gets NaN (interpolation.py:277)
+        for (int v = 0; v < nv; v++) {
+            if (raw_out) raw_out[(long)v * n + u] = code < 0 ? -9999.f : qnan;
+            if (vals) vals[(long)mv.var_of_slot[v] * plane + u] = qnan;
+        }
+        return;
+    }
+    float fz[4], hz[4];
+    const float *dp[4];
+    for (int j = 0; j < 4; j++) {
+        const float *zc = mv.zcol + cell[j] * nz + c1[j];
+        float za = zc[0], zb = zc[1];
+        fz[j] = za - zb;
+        hz[j] = H - zb;
+        dp[j] = mv.dcol + (cell[j] * nz + c1[j]) * nv;
+    }
+    for (int v = 0; v < nv; v++) {
+        float w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float va = dp[j][v], vb = dp[j][nv + v];
+            w[j] = vb - (vb - va) / fz[j] * hz[j];
+        }
+        float o = dx * dy * w[0] + x * w[2] * dy + dx * w[1] * y + x * y * w[3];
+        if (raw_out) raw_out[(long)v * n + u] = o;
+        if (vals) vals[(long)mv.var_of_slot[v] * plane + u] = o;
+    }
+}
+
+void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coords, const float *H,
+                   float *vals, long plane, signed char *mask, float *raw_out)
+{
+    hipLaunchKernelGGL(k_interp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mv, n, coords, H, vals,
+                       plane, mask, raw_out);
+}
+
+// =============================================================================
+// PSD set-up per (gate, sub-beam, class): valid test, nearest lookup-table node,
+// PSD parameters (hydrometeors.py set_psd), bucket histogram; Doppler scheme 1
+// radial velocity per sub-beam.
+// =============================================================================
+__device__ inline int nearest_node(float x, float lo, float step, int n)
+{   // lut.py:240-241: np.round (half to even) of float32 (x - lo) / step, clamped
+    float c = rintf((x - lo) / step);
+    c = fminf(fmaxf(0.f, c), (float)(n - 1));
+    return (int)c;
+}
+
+__device__ inline float fold_elev(float e)
+{   // scattering_sz.py:66-68
+    if (e > 90.f) e = 180.f - e;
+    if (e < 0.f) e = -e;
+    return e;
+}
+
+// lambda and N0 of one class at one gate (float64, float32 where the reference's
+// NumPy promotion keeps float32).  Returns false when Q is not usable.
+__device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, double *lam, double *n0)
+{
+    if (p.kind == 0) {
+        *lam = pow(p.lambda_factor / (double)q, 1. / (4. + p.mu));
+        *n0 = p.n0_fixed;
+    } else if (p.kind == 1) {
+        // exp through float64 so that subnormal float32 results are kept, as glibc's expf keeps them
+        float n0f = 13.5f * (565000.0f * (float)exp((double)(-0.107f * (T - 273.15f)))) / 1000.f;
+        float an0 = (float)p.a * n0f;
+        *lam = pow((double)an0 * p.lambda_factor / (double)q, 1. / (p.b + 1));
+        *n0 = (double)n0f;
+    } else {
+        float xm = q * 1.0f / (qn + 1.1920929e-07f);
+        xm = fminf(fmaxf(xm, (float)p.x_min), (float)p.x_max);
+        double l = pow(p.lambda_factor * (double)xm, -p.nu / p.b);
+        double n = (p.nu / p.ntot_factor) * (double)qn * pow(l, (p.mu + 1) / p.nu);
+        *n0 = n * pow(1000., -(1 + p.mu));
+        *lam = l * pow(1000., -p.nu);
+    }
+    return true;
+}
+
+// Position of the run of equal keys this lane belongs to inside its wave.
+__device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
+{
+    int prev = __shfl_up(k, 1);
+    bool head = (lane == 0) || (k != prev);
+    unsigned long long hb = __ballot(head);
+    unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
+    int hl = 63 - __clzll(hb & upto);
+    unsigned long long above = (hl == 63) ? 0ull : (hb & ~((2ull << hl) - 1));
+    int end = above ? (__ffsll((long long)above) - 1) : 64;
+    *head_lane = hl;
+    *len = end - hl;
+}
+
+__global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
+                       const float *__restrict__ elev, const signed char *__restrict__ mask,
+                       const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi, int doppler,
+                       int *__restrict__ key, float2 *__restrict__ lam, double *__restrict__ coef,
+                       int *__restrict__ hist, double *__restrict__ vr)
+{
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    bool live = u < nu;
+    long uu = live ? u : 0;
+    long rb = uu / n_gates;
+    int b = (int)(rb % n_sub);
+    float T = vals[(long)CPOL_V_T * plane + uu];
+    float e_raw = elev[uu];
+    float e = fold_elev(e_raw);
+    double w = wsub[b];
+    for (int h = 0; h < ct.n_cls; h++) {
+        const PsdView &p = ct.psd[h];
+        const LutView &lv = ct.lut[h];
+        float q = vals[(long)p.q_var * plane + uu];
+        float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
+        bool valid = live && (q > 0.f);
+        int k = -1;
+        if (valid) {
+            int ie = nearest_node(e, lv.e_min, lv.e_step, lv.n_e);
+            int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
+            k = (h * ct.ne_max + ie) * ct.nt_max + it;
+            double l, n0;
+            psd_params(p, q, qn, T, &l, &n0);
+            double l2 = l * 1.4426950408889634;            // exponent in base 2
+            float hi = (float)l2;
+            float lo = (float)(l2 - (double)hi);
+            lam[(long)h * nu + u] = make_float2(hi, lo);
+            coef[(long)h * nu + u] = n0 * (double)lv.dD * w;
+        }
+        if (live) key[(long)h * nu + u] = k;
+        int hl, len;
+        wave_run(k, lane, &hl, &len);
+        if (k >= 0 && hl == lane) atomicAdd(&hist[k], len);
+    }
+    if (doppler == 1 && live) {
+        // doppler_sz.py:130-153 (closed-form PSD-weighted fall speed) and :75-87 (projection)
+        double vh = __builtin_nan(""), nn = __builtin_nan("");
+        for (int h = 0; h < ct.n_cls; h++) {
+            const PsdView &p = ct.dop[h];
+            float q = vals[(long)p.q_var * plane + uu];
+            float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
+            double l, n0, vi, ni;
+            float Tp = vals[(long)p.t_var * plane + uu];
+            psd_params(p, q, qn, Tp, &l, &n0);
+            if (q == 0.f) l = __builtin_nan("");
+            vi = p.vel_factor * n0 * p.alpha / p.nu * pow(l, -(p.beta + p.mu + 1) / p.nu);
+            if (p.kind == 2) ni = (double)qn;
+            else ni = p.ntot_factor * n0 / p.nu * pow(l, -(p.mu + 1) / p.nu);
+            // nansum_arr: NaN counts as 0 once anything was added (utilities.py:46-66)
+            vh = (vh != vh ? 0. : vh) + (vi != vi ? 0. : vi);
+            nn = (nn != nn ? 0. : nn) + (ni != ni ? 0. : ni);
+        }
+        float rho = vals[(long)CPOL_V_RHO * plane + uu];
+        float rho0 = vals[(long)CPOL_V_RHO * plane + rb * n_gates];
+        float rc = sqrtf(rho / rho0);
+        double vhyd = vh / nn * (double)rc;
+        float th = e_raw * (float)(M_PI / 180.0);
+        double ph = phi[rb] * (M_PI / 180.0);
+        double U = vals[(long)CPOL_V_U * plane + uu], V = vals[(long)CPOL_V_V * plane + uu];
+        double W = vals[(long)CPOL_V_W * plane + uu];
+        vr[u] = (U * sin(ph) + V * cos(ph)) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
+    }
+}
+
+void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
+                 const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
+                 const double *phi, int doppler, int *key, float2 *lam, double *coef, int *hist, double *vr)
+{
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, ct, nu, n_gates, vals, plane,
+                       elev, mask, weight_per_sub, n_sub, phi, doppler, key, lam, coef, hist, vr);
+}
+
+// Exclusive scan of the bucket histogram (nb <= 8192) -> offsets, scatter cursors and
+// the chunk table of the integrate kernel.  One workgroup.
+__global__ void k_scan(int nb, const int *__restrict__ hist, int *__restrict__ offs, int *__restrict__ cursor,
+                       int *__restrict__ chunk_off)
+{
+    __shared__ int s_a[1024], s_b[1024];
+    int t = threadIdx.x;
+    int per = (nb + 1023) / 1024;
+    int a = 0, c = 0;
+    for (int i = 0; i < per; i++) {
+        int j = t * per + i;
+        int v = j < nb ? hist[j] : 0;
+        a += v;
+        c += (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
+    }
+    s_a[t] = a; s_b[t] = c;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int va = t >= d ? s_a[t - d] : 0, vb = t >= d ? s_b[t - d] : 0;
+        __syncthreads();
+        s_a[t] += va; s_b[t] += vb;
+        __syncthreads();
+    }
+    int ea = s_a[t] - a, eb = s_b[t] - c;
+    for (int i = 0; i < per; i++) {
+        int j = t * per + i;
+        if (j < nb) {
+            int v = hist[j];
+            offs[j] = ea; cursor[j] = ea; chunk_off[j] = eb;
+            ea += v;
+            eb += (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
+        }
+    }
+    if (t == 1023) { offs[nb] = s_a[1023]; chunk_off[nb] = s_b[1023]; }
+}
+
+void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nb, hist, offs, cursor, chunk_off);
+}
+
+__global__ void k_scatter(long nslots, const int *__restrict__ key, int *__restrict__ cursor, int *__restrict__ sorted)
+{
+    long sidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    int k = sidx < nslots ? key[sidx] : -1;
+    int hl, len;
+    wave_run(k, lane, &hl, &len);
+    int base = 0;
+    if (k >= 0 && hl == lane) base = atomicAdd(&cursor[k], len);
+    base = __shfl(base, hl);
+    if (k >= 0) sorted[base + (lane - hl)] = (int)sidx;
+}
+
+void launch_scatter(hipStream_t s, long nslots, const int *key, int *cursor, int *sorted)
+{
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, nslots, key, cursor, sorted);
+}
+
+// =============================================================================
+// PSD integration (scattering_sz.py:76-103): for every unit of one (class, e-node,
+// t-node) bucket   r[k] = sum_d  sz[d][k] * D_d^mu * exp(-lambda * D_d^nu),  k < 12
+// as an [units x 1024] . [1024 x 16] contraction on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32).  The bucket's table slice lives in LDS; every lane
+// generates one N(D) value per MFMA (A operand), so nothing is computed twice.
+// =============================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define INTEG_THREADS 256
+#define LDS_B_FLOATS (1024 * CPOL_N_COL)
+
+__global__ __launch_bounds__(INTEG_THREADS, 2)
+void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
+                 const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
+{
+    __shared__ __attribute__((aligned(16))) float lds[LDS_B_FLOATS + 1024];
+    float *ldsB = lds;                 // [64 quads][64 lanes][4 steps]
+    float *ldsX = lds + LDS_B_FLOATS;  // [64 quads][4 k][4 steps]
+
+    // XCD-aware chunk order: workgroups that share an XCD (blockIdx % 8) take consecutive
+    // chunks, i.e. mostly the same table slice, so the slice is fetched into one L2.
+    const int total = chunk_off[nb];
+    const unsigned nwg = gridDim.x, orig = blockIdx.x;
+    const unsigned q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+    const unsigned cid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+    if ((int)cid >= total) return;
+
+    // bucket of this chunk: last b with chunk_off[b] <= cid
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= (int)cid) lo = mid; else hi = mid;
+    }
+    // buckets with zero chunks share chunk_off with their successor: take the last one
+    const int bkt = lo;
+    const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
+    int cnt = offs[bkt + 1] - start;
+    if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
+
+    const int it = bkt % ct.nt_max;
+    const int ie = (bkt / ct.nt_max) % ct.ne_max;
+    const int h = bkt / (ct.nt_max * ct.ne_max);
+    const LutView lv = ct.lut[h];
+    const int tid = threadIdx.x;
+
+    // ---- stage the slice: B'[d][k] = sz[d][k] * D_d^mu, permuted so that a lane's four
+    // consecutive MFMA steps are one 16-byte LDS read ----
+    {
+        const float4 *src = (const float4 *)(lv.table + ((long)(ie * lv.n_t + it) * lv.n_d) * CPOL_N_SZ);
+        for (int i = tid; i < 1024 * 3; i += INTEG_THREADS) {
+            float4 v = src[i];
+            int d = i / 3, k4 = (i % 3) * 4;
+            float m = lv.xmu[d];
+            int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
+            float *dst = ldsB + ((qd * 64 + kk * 16 + k4) * 4 + s4);
+            dst[0] = v.x * m; dst[4] = v.y * m; dst[8] = v.z * m; dst[12] = v.w * m;
+        }
+        for (int i = tid; i < 1024; i += INTEG_THREADS) {
+            int qd = i >> 4, s4 = (i >> 2) & 3, kk = i & 3;
+            float *dst = ldsB + ((qd * 64 + kk * 16 + 12) * 4 + s4);
+            dst[0] = 0.f; dst[4] = 0.f; dst[8] = 0.f; dst[12] = 0.f;
+            ldsX[i] = lv.xq[i];
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ngroups = (cnt + 15) >> 4;
+    const float4 *B4 = (const float4 *)ldsB;
+    const float4 *X4 = (const float4 *)ldsX;
+    const float nln2 = -0.6931471805599453f;
+
+    for (int g0 = wave * 2; g0 < ngroups; g0 += 8) {
+        // two groups of 16 units per pass (two independent accumulators)
+        int ua = g0 * 16 + (lane & 15), ub = ua + 16;
+        float2 la = make_float2(0.f, 0.f), lb = la;
+        if (ua < cnt) la = lam[sorted[start + ua]];
+        if (ub < cnt) lb = lam[sorted[start + ub]];
+        double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+        for (int qo = 0; qo < 64; qo += 8) {
+            f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int qd = qo; qd < qo + 8; qd++) {
+                float4 bq = B4[qd * 64 + lane];
+                float4 xq = X4[qd * 4 + (lane >> 4)];
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+                const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    float x = xx[s4];
+                    float pa = la.x * x, pb = lb.x * x;
+                    float ra = fmaf(la.x, x, -pa), rb = fmaf(lb.x, x, -pb);
+                    ra = fmaf(la.y, x, ra); rb = fmaf(lb.y, x, rb);
+                    float ea = __builtin_amdgcn_exp2f(-pa), eb = __builtin_amdgcn_exp2f(-pb);
+                    float na = fmaf(ea, ra * nln2, ea), nb_ = fmaf(eb, rb * nln2, eb);
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na, bb[s4], acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_, bb[s4], accb, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
+        }
+        // C/D layout: column = lane & 15 (component), row = (lane >> 4) * 4 + r (unit in group)
+        const int col = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = (lane >> 4) * 4 + r;
+            int u0 = g0 * 16 + row, u1 = u0 + 16;
+            if (u0 < cnt) psd_out[(long)sorted[start + u0] * CPOL_N_COL + col] = (float)da[r];
+            if (u1 < cnt) psd_out[(long)sorted[start + u1] * CPOL_N_COL + col] = (float)db[r];
+        }
+    }
+}
+
+void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
+                      const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out)
+{
+    if (max_chunks <= 0) return;
+    hipLaunchKernelGGL(k_integrate, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
+                       sorted, lam, psd_out);
+}
+
+// =============================================================================
+// per-ray reduction: GH-weighted sub-beam sum with the reference's float32 storage
+// (scattering_sz.py:38,105), class sum (:109-110), observables (:164-196), the two
+// range scans (:117-125) as wavefront prefix scans, mask (:144-151), Doppler
+// scheme 1/2 averaging (doppler_sz.py:62-87), sensitivity cut (utilities.py:68-105).
+// One wavefront per ray; lanes stride the gates.
+// =============================================================================
+__device__ inline double wave_scan_incl(double x, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        double t = __shfl_up(x, off);
+        if (lane >= off) x += t;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(64)
+void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
+                   const float *__restrict__ psd_out, const signed char *__restrict__ mask,
+                   const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
+                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int G = op.n_gates, B = op.n_sub;
+    const float qnan = __builtin_nanf("");
+    double carry_phi = 0, carry_h = 0, carry_v = 0;
+    for (int g0 = 0; g0 < G; g0 += 64) {
+        const int g = g0 + lane;
+        const bool act = g < G;
+        float tot[CPOL_N_SZ];
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) tot[k] = 0.f;
+        double msum = 0, rv = __builtin_nan(""), sw = 0;
+        if (act) {
+            for (int h = 0; h < op.n_cls; h++) {
+                float acc[CPOL_N_SZ];
+#pragma unroll
+                for (int k = 0; k < CPOL_N_SZ; k++) acc[k] = qnan;
+                for (int b = 0; b < B; b++) {
+                    long u = ((long)r * B + b) * G + g;
+                    long slot = (long)h * nu + u;
+                    if (key[slot] < 0) continue;
+                    double c = coef[slot];
+                    const float4 *p = (const float4 *)(psd_out + slot * CPOL_N_COL);
+                    float4 v0 = p[0], v1 = p[1], v2 = p[2];
+                    const float vv[CPOL_N_SZ] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+                    for (int k = 0; k < CPOL_N_SZ; k++) {
+                        double v = (double)vv[k] * c;
+                        double s = (acc[k] != acc[k] ? 0. : (double)acc[k]) + (v != v ? 0. : v);
+                        acc[k] = (float)s;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CPOL_N_SZ; k++) tot[k] += (acc[k] != acc[k]) ? 0.f : acc[k];
+            }
+            for (int b = 0; b < B; b++) {
+                long u = ((long)r * B + b) * G + g;
+                msum += (double)mask[u];
+                if (op.doppler) {
+                    double pw = vr[u], w = wsub[b];
+                    sw += (pw != pw) ? 0. : w;
+                    double t = pw * w;
+                    rv = (rv != rv ? 0. : rv) + (t != t ? 0. : t);
+                }
+            }
+        }
+        float s[CPOL_N_SZ];
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) s[k] = (tot[k] == 0.f) ? qnan : tot[k];
+        // get_pol_from_sz, float32 in the reference's order
+        float bq = ((s[0] - s[1]) - s[2]) + s[3];
+        float cq = ((s[0] + s[1]) + s[2]) + s[3];
+        float xs_h = op.two_pi * bq, xs_v = op.two_pi * cq;
+        float zh = op.zfac * xs_h, zv = op.zfac * xs_v;
+        float zdr = xs_h / xs_v;
+        float kdp = op.kdpfac * (s[10] - s[8]);
+        float ah = op.afac * (op.two_wl * s[11]);
+        float av = op.afac * (op.two_wl * s[9]);
+        float a1 = s[4] + s[7], a2 = s[6] - s[5];
+        float aq = a1 * a1 + a2 * a2;
+        float rhohv = sqrtf(aq / (bq * cq));
+        float delta = atan2f(s[5] - s[6], (-s[4]) - s[7]);
+        float kdpm = kdp + delta;
+        // PHIDP = cumsum(nan->0 of 2*KDP_m) * res / 1000
+        float two_k = 2.f * kdpm;
+        double xphi = (act && two_k == two_k) ? (double)two_k : 0.;
+        double sc = wave_scan_incl(xphi, lane) + carry_phi;
+        carry_phi = __shfl(sc, 63);
+        float phidp = (float)sc * op.res / 1000.f;
+        if (op.att_corr) {
+            // cumprod(nan->1 of 10^(-0.1*A*res_km)) = 10^(cumsum of the exponents)
+            float eh = (-0.1f * ah) * op.res_km, ev = (-0.1f * av) * op.res_km;
+            double xh = (act && eh == eh) ? (double)eh : 0., xv = (act && ev == ev) ? (double)ev : 0.;
+            double sh = wave_scan_incl(xh, lane) + carry_h, sv = wave_scan_incl(xv, lane) + carry_v;
+            carry_h = __shfl(sh, 63); carry_v = __shfl(sv, 63);
+            zv *= (float)exp10(sv);
+            zh *= (float)exp10(sh);
+            zdr = zh / zv;
+        }
+        double rvel = rv / sw;
+        if (op.sens_mode && act) {
+            double thr;
+            if (op.sens_mode == 1) thr = op.sens0;
+            else thr = (op.sens0 - 20 * log10(op.sens1 / 1000.)) + 20 * log10((op.res_d * g) / 1000.);
+            float zdb = 10.f * log10f(zh);
+            if ((double)zdb < thr) {
+                zh = qnan; zv = qnan; phidp = qnan; zdr = qnan; rhohv = qnan; kdpm = qnan;
+                rvel = __builtin_nan("");
+            }
+        }
+        if (act) {
+            long o = (ray0 + r) * (long)G + g;
+            if (obs) {
+                obs[CPOL_O_ZH * obs_plane + o] = zh;
+                obs[CPOL_O_ZDR * obs_plane + o] = zdr;
+                obs[CPOL_O_ZV * obs_plane + o] = zv;
+                obs[CPOL_O_KDP * obs_plane + o] = kdpm;
+                obs[CPOL_O_DELTA_HV * obs_plane + o] = delta;
+                obs[CPOL_O_PHIDP * obs_plane + o] = phidp;
+                obs[CPOL_O_RHOHV * obs_plane + o] = rhohv;
+                obs[CPOL_O_AH * obs_plane + o] = ah;
+                obs[CPOL_O_AV * obs_plane + o] = av;
+            }
+            if (mask_out) {
+                double m = msum / (double)B;
+                if (m >= 0 && m < 1) m = 0;
+                mask_out[o] = m;
+            }
+            if (rvel_out && op.doppler) rvel_out[o] = rvel;
+        }
+    }
+}
+
+void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
+                        const double *coef, const float *psd_out, const signed char *mask,
+                        const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
+                        long ray0, double *mask_out, double *rvel_out)
+{
+    hipLaunchKernelGGL(k_observables, dim3(n_rays), dim3(64), 0, s, op, n_rays, nu, key, coef, psd_out, mask,
+                       weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out);
+}
+
+// geometry of the central sub-beam (scattering_sz.py:154-157)
+__global__ void k_gather_central(int n_rays, int n_sub, int n_gates, const float *__restrict__ S,
+                                 const float *__restrict__ H, const double *__restrict__ lat,
+                                 const double *__restrict__ lon, float *dist, float *height, double *olat,
+                                 double *olon, long ray0)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)n_rays * n_gates) return;
+    int r = (int)(t / n_gates), g = (int)(t % n_gates);
+    long u = ((long)r * n_sub + n_sub / 2) * n_gates + g;
+    long o = (ray0 + r) * (long)n_gates + g;
+    if (dist) dist[o] = S[u];
+    if (height) height[o] = H[u];
+    if (olat) olat[o] = lat[u];
+    if (olon) olon[o] = lon[u];
+}
+
+void launch_gather_central(hipStream_t s, int n_rays, int n_sub, int n_gates, const float *S, const float *H,
+                           const double *lat, const double *lon, float *dist, float *height, double *olat,
+                           double *olon, long ray0)
+{
+    long n = (long)n_rays * n_gates;
+    hipLaunchKernelGGL(k_gather_central, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_rays, n_sub, n_gates,
+                       S, H, lat, lon, dist, height, olat, olon, ray0);
+}
+
+// doppler_c.c:11-33, one thread per velocity bin (three classes, stride 3)
+__global__ void k_get_refl(float *refl, int nbins, const float *Da, const float *Db, const float *D, const float *rcs,
+                           const float *N0, const float *mu, const float *lam, const float *nu, const float *step,
+                           const float *dmin)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    float out = 0.f;
+    for (int j = 0; j < 3; j++) {
+        if (lam[j] > 0) {
+            float sum = 0;
+            int ia = (int)((Da[i * 3 + j] - dmin[j]) / step[j]);
+            int ib = (int)((Db[i * 3 + j] - dmin[j]) / step[j]);
+            for (int k = ia; k < ib; k++) {
+                double d = D[k * 3 + j];
+                sum = (float)((double)sum + pow(d, (double)mu[j]) * exp(-(double)lam[j] * pow(d, (double)nu[j])) * (double)rcs[k * 3 + j]);
+            }
+            out += sum * step[j] * N0[j];
+        }
+    }
+    refl[i] = out;
+}
+
+void launch_get_refl(hipStream_t s, float *refl, int nbins, const float *Da, const float *Db, const float *D,
+                     const float *rcs, const float *N0, const float *mu, const float *lam, const float *nu,
+                     const float *step, const float *dmin)
+{
+    hipLaunchKernelGGL(k_get_refl, dim3((nbins + 63) / 64), dim3(64), 0, s, refl, nbins, Da, Db, D, rcs, N0, mu, lam,
+                       nu, step, dmin);
+}

@@ -1,0 +1,102 @@
+"""Host-side driver of one GPU context: turns the reference-style configuration
+dictionary, lookup tables and model state into C-ABI uploads (cosmo_pol_amd._lib).
+"""
+import numpy as np
+
+from . import _lib
+from . import constants as cst
+from . import hydrometeors
+
+
+def earth_radius(latitude):
+    """refraction/atm_refraction.py:18-21."""
+    a = 6378.1370 * 1000
+    b = 6356.7523 * 1000
+    return np.sqrt(((a ** 2 * np.cos(latitude)) ** 2 + (b ** 2 * np.sin(latitude)) ** 2) /
+                   ((a * np.cos(latitude)) ** 2 + (b * np.sin(latitude)) ** 2))
+
+
+def radar_ranges(conf):
+    r = conf['radar']
+    return np.arange(r['radial_resolution'] / 2, r['range'], r['radial_resolution'])
+
+
+def gauss_hermite_subbeams(conf):
+    """Sub-beams of integration scheme 1 (interpolation/interpolation.py:67-85,226-236,260-266):
+    returns (az_off, el_off, weight) of the kept points, horizontal index outer, vertical inner."""
+    bw = conf['radar']['3dB_beamwidth']
+    nh, nv = int(conf['integration']['nh_GH']), int(conf['integration']['nv_GH'])
+    sigma = bw / (2 * np.sqrt(2 * np.log(2)))
+    ph, wh = np.polynomial.hermite.hermgauss(nh)
+    pv, wv = np.polynomial.hermite.hermgauss(nv)
+    ph, pv = ph * sigma, pv * sigma                      # no sqrt(2): as the reference
+    w = np.outer(wh * sigma, wv * sigma)
+    w *= np.abs(np.cos(pv))                              # degrees fed to cos: as the reference
+    total = np.sum(w.ravel())
+    ws = np.sort(w.ravel())[::-1]
+    wc = np.cumsum(ws / total)
+    wc[-1] = 1.
+    thr = ws[np.where(wc >= conf['integration']['weight_threshold'])[0][0]]
+    total = np.sum(ws[ws >= thr])
+    broad = nh > 1 or nv > 1
+    az, el, ww = [], [], []
+    for i in range(nh):
+        for j in range(nv):
+            if w[i, j] >= thr or not broad:
+                az.append(ph[i]); el.append(pv[j]); ww.append(w[i, j] / total)
+    return np.array(az), np.array(el), np.array(ww)
+
+
+class Engine(object):
+    def __init__(self, conf, device=0):
+        self.ctx = _lib.Context(device)
+        self.conf = None
+        self.configure(conf)
+
+    def configure(self, conf, doppler=None, sensitivity_cut=False):
+        r = conf['radar']
+        rr = radar_ranges(conf)
+        wl = cst.C / (r['frequency'] * 1E09) * 1000
+        dscheme = conf['doppler']['scheme'] if doppler is None else doppler
+        sens = r['sensitivity']
+        if not isinstance(sens, (list, tuple)):
+            sens = [sens]
+        mode = 0
+        if sensitivity_cut:
+            mode = len(sens) if len(sens) in (1, 2) else 0
+        self.ctx.set_config(radar_lat=float(r['coords'][0]), radar_lon=float(r['coords'][1]),
+                            radar_alt=float(r['coords'][2]), range_res=float(r['radial_resolution']),
+                            earth_radius=float(earth_radius(r['coords'][1])), n_gates=len(rr),
+                            wavelength_mm=float(wl), kw=cst.KW,
+                            attenuation_correction=int(conf['attenuation']['correction']),
+                            microphysics_scheme=int(conf['microphysics']['scheme']),
+                            doppler_scheme=int(dscheme), sensitivity_mode=mode,
+                            sensitivity=(float(sens[0]), float(sens[1]) if len(sens) > 1 else 0.))
+        self.conf = conf
+        self.n_gates = len(rr)
+
+    def set_gauss_hermite(self):
+        az, el, w = gauss_hermite_subbeams(self.conf)
+        self.ctx.set_quadrature(az, el, w)
+        return az, el, w
+
+    def upload_luts(self, lut_sz):
+        """lut_sz: {class letter: Lookup_table-like with axes e, t, d, sz}."""
+        scheme = self.conf['microphysics']['scheme']
+        for h in hydrometeors.hydrom_types(scheme):
+            lut = lut_sz[h]
+            ie, it, idd = lut.axes_names['e'], lut.axes_names['t'], lut.axes_names['d']
+            tab = np.asarray(lut.value_table)
+            order = (ie, it, idd, lut.axes_names['sz'])
+            if order != (0, 1, 2, 3):
+                tab = np.transpose(tab, order)
+            pol = hydrometeors.create_hydrometeor(h, '2mom' if scheme == 2 else '1mom')
+            dop = hydrometeors.create_hydrometeor(h, scheme)      # doppler_sz.py:57 passes the integer
+            self.ctx.upload_lut(h, lut.axes_limits[ie][0], lut.axes_step[ie], lut.axes_limits[it][0],
+                                lut.axes_step[it], lut.axes[idd], tab, pol.psd_descriptor(), dop.doppler_descriptor(scheme))
+
+    def upload_model(self, fields, zlev, proj_info, resolution):
+        llc = (float(proj_info['Lo1']), float(proj_info['La1']))
+        urc = (float(proj_info['Lo2']), float(proj_info['La2']))
+        pole = (float(proj_info['Latitude_of_southern_pole']), float(proj_info['Longitude_of_southern_pole']))
+        self.ctx.upload_model(fields, zlev, llc, urc, resolution, pole)

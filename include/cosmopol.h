@@ -1,0 +1,189 @@
+/* cosmopol.h -- C ABI of libcosmopol_hip.so: the MI355X (gfx950) implementation of the
+ * cosmo_pol per-gate forward-operator hot path.
+ *
+ * Plain C types only; every function returns an int status (CPOL_OK = 0) unless it
+ * mirrors a reference symbol.  Pointers are HOST pointers unless a parameter name ends
+ * in _dev.  The library owns all device memory inside a cpol_ctx; a ctx belongs to one
+ * device and must not be used from two threads at once.  No host pointer is retained
+ * after a call returns.
+ *
+ * Each entry point cites the reference interface it stands in for (paths relative to
+ * the reference root).
+ */
+#ifndef COSMOPOL_H
+#define COSMOPOL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPOL_OK 0
+#define CPOL_ERR_ARG 1        /* bad argument / shape mismatch */
+#define CPOL_ERR_HIP 2        /* a HIP runtime call failed (see cpol_last_error) */
+#define CPOL_ERR_STATE 3      /* model / LUT / config not uploaded yet */
+#define CPOL_ERR_DOMAIN 4     /* a gate lies outside the model domain (reference: IndexError,
+                                 interpolation/interpolation.py:359-363) */
+
+#define CPOL_MAX_CLASSES 4    /* R, S, G, H (scatter/scattering_sz.py:32-35) */
+#define CPOL_MAX_VARS 16
+#define CPOL_N_SZ 12          /* scattering components per diameter (lookup/compute_lut_sz.py:83-94) */
+#define CPOL_N_OBS 9          /* ZH ZDR ZV KDP DELTA_HV PHIDP RHOHV AH AV (scattering_sz.py:130-139) */
+
+typedef struct cpol_ctx cpol_ctx;
+
+/* Variable slots of the model state (radar_operator.py:32-33, BASE_VARIABLES[_2MOM]). */
+enum cpol_var {
+    CPOL_V_U = 0, CPOL_V_V, CPOL_V_W, CPOL_V_QR, CPOL_V_QS, CPOL_V_QG, CPOL_V_RHO, CPOL_V_T,
+    CPOL_V_QH, CPOL_V_QNH, CPOL_V_QNR, CPOL_V_QNS, CPOL_V_QNG, CPOL_V_COUNT
+};
+
+/* Order of the observables in every output array. */
+enum cpol_obs {
+    CPOL_O_ZH = 0, CPOL_O_ZDR, CPOL_O_ZV, CPOL_O_KDP, CPOL_O_DELTA_HV, CPOL_O_PHIDP,
+    CPOL_O_RHOHV, CPOL_O_AH, CPOL_O_AV
+};
+
+/* POD mirror of the utilities/cfg.py CONFIG keys the hot path reads, plus the derived
+ * constants of constants/constants.py:73-77. */
+typedef struct {
+    double radar_lat, radar_lon, radar_alt;   /* radar.coords */
+    double range_res;                         /* radar.radial_resolution [m] */
+    double earth_radius;                      /* refraction/atm_refraction.py:18-21 evaluated as at :114-117;
+                                                 0 = let the library evaluate it */
+    int    n_gates;                           /* len(arange(res/2, range, res)) */
+    double wavelength_mm;                     /* constants.WAVELENGTH */
+    double kw;                                /* constants.KW */
+    int    attenuation_correction;            /* attenuation.correction */
+    int    microphysics_scheme;               /* 1 or 2 */
+    int    doppler_scheme;                    /* 0 = skip, 1, 2 (3: see cpol_doppler_spectrum) */
+    int    sensitivity_mode;                  /* 0 = no cut, 1 = scalar, 2 = [ZH, range] (utilities.py:74-81) */
+    double sensitivity[2];
+} cpol_config;
+
+/* Per-class particle-size-distribution constants (hydrometeors/hydrometeors.py:177-438,
+ * constants/constants_1mom.py, constants_2mom.py).  psd_kind selects the set_psd branch:
+ *   0: 1-moment rain / graupel   lambda = (lambda_factor / Q)^(1/(4+mu)),  N0 fixed
+ *   1: 1-moment snow             N0(T), lambda = (a N0 lambda_factor / Q)^(1/(b+1))
+ *   2: 2-moment (any class)      x = clamp(Q/(QN+eps)), lambda, N0 from (QN, Q)
+ * The *_dop members describe the class as doppler_sz.py:57 instantiates it (always
+ * 1-moment except hail). */
+typedef struct {
+    int    psd_kind;
+    double a, b, alpha, beta, mu, nu;
+    double lambda_factor, vel_factor, ntot_factor;
+    double n0_fixed;
+    double x_min, x_max;
+    double d_min, d_max;
+    int    q_var, qn_var;          /* cpol_var slots of the mass / number density arguments of set_psd (-1 if unused) */
+    int    t_var;                  /* slot of the temperature argument of the 1-moment snow branch (normally CPOL_V_T;
+                                      with 2-moment input doppler_sz.py:143 hands QNS_v to that argument) */
+} cpol_psd;
+
+typedef struct {
+    int     n_e, n_t, n_d;          /* table is [n_e][n_t][n_d][12] float32 */
+    float   e_min, e_step;          /* axes_limits[0], axes_step of lookup/lut.py:114-115 (float32) */
+    float   t_min, t_step;
+    const float *d_axis;            /* n_d diameters (float32) */
+    const float *table;
+} cpol_lut;
+
+/* ---- life cycle ------------------------------------------------------------------- */
+int  cpol_create(int device, cpol_ctx **ctx);
+int  cpol_destroy(cpol_ctx *ctx);
+const char *cpol_last_error(cpol_ctx *ctx);
+/* HIP stream all kernels of this ctx are launched on (a hipStream_t), for event timing. */
+void *cpol_stream(cpol_ctx *ctx);
+int  cpol_synchronize(cpol_ctx *ctx);
+
+/* ---- state -------------------------------------------------------------------------- */
+/* utilities/cfg.py CONFIG + constants.update() (radar_operator.py:39-40). */
+int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg);
+
+/* Model state: what radar_operator.py:86-151 (load_model_file) keeps in dic_vars.
+ * var_ids[i] is the cpol_var slot of data[i]; every array is [nz][ny][nx] float32 with
+ * level 0 = model top.  llc/urc = (Lo1, La1)/(Lo2, La2), res = (dlon, dlat),
+ * pole = (Latitude_of_southern_pole, Longitude_of_southern_pole). */
+int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, const float *const *data,
+                      const float *zlev, int nz, int ny, int nx,
+                      const float llc[2], const float urc[2], const float res[2], const double pole[2]);
+
+/* One hydrometeor class: its lookup table (lookup/lut.py:79-245, `lut_sz[h]`) and its PSD
+ * constants for the polarimetric path (psd) and for the Doppler path (psd_doppler).
+ * cls = 0..3 for R, S, G, H. */
+int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,
+                    const cpol_psd *psd_doppler);
+
+/* Antenna quadrature: the kept sub-beams of interpolation/interpolation.py:260-279 in
+ * reference order, as offsets (degrees) added to the ray's azimuth / elevation and
+ * normalised weights.  The central sub-beam is index n_sub/2 (scattering_sz.py:25). */
+int cpol_set_quadrature(cpol_ctx *ctx, int n_sub, const double *az_off, const double *el_off,
+                        const double *weight);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+/* One call = what the pool workers of radar_operator.py:237-256 do for n_rays rays:
+ * get_profiles_GH -> get_doppler_velocity -> get_radar_observables (+ cut_at_sensitivity
+ * when sensitivity_mode != 0).  Outputs (any may be NULL) are [.. n_rays][n_gates]:
+ *   obs   float32 [CPOL_N_OBS][n_rays][n_gates]   linear units, NaN where undefined
+ *   rvel  float64 [n_rays][n_gates]               (doppler_scheme 1 or 2)
+ *   mask  float64 [n_rays][n_gates]               scattering_sz.py:144-151
+ *   lat, lon float64, dist, height float32 [n_rays][n_gates]   central sub-beam geometry
+ * ray_status int32 [n_rays]: CPOL_OK or CPOL_ERR_DOMAIN per ray.
+ * cpol_run_rays copies to host buffers; cpol_run_rays_dev leaves results in ctx-owned
+ * device buffers (valid until the next call) and returns their addresses. */
+typedef struct {
+    float  *obs;
+    double *rvel;
+    double *mask;
+    double *lat, *lon;
+    float  *dist, *height;
+    int    *ray_status;
+} cpol_outputs;
+
+int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                  cpol_outputs *host_out);
+int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                      cpol_outputs *dev_out);
+
+/* ---- stage-level entry points (unit parity against the reference functions) ---------- */
+/* refraction/atm_refraction.py:110-123 (ref_4_3), pyproj Geod.fwd at
+ * interpolation/interpolation.py:316-325 and the rotated-pole transform of :355 for every
+ * (ray, sub-beam, gate).  Arrays are [n_rays][n_sub][n_gates]; coords_rot is [..][2] =
+ * (rlat, rlon) float32, the exact operand the reference hands to get_all_radar_pts. */
+int cpol_geolocate(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                   float *dist, float *height, float *elev, double *lat, double *lon,
+                   float *coords_rot, int *ray_status);
+
+/* interpolation/interpolation_c.c:12 (get_all_radar_pts) on the uploaded model for n points
+ * and every uploaded variable: out is [nvars][n] in upload order; -9999 above the domain,
+ * NaN below terrain, exactly like the reference. */
+int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords_rot, const float *heights, float *out);
+
+/* scatter/scattering_sz.py:17 (get_radar_observables) on caller-supplied sub-beam profiles,
+ * i.e. on the list[Beam] that get_profiles_GH returns.  values is [CPOL_V_COUNT][n_sub][n_gates]
+ * (slots that the scheme does not use are ignored), elev/mask are [n_sub][n_gates], weight
+ * [n_sub].  obs float32 [CPOL_N_OBS][n_gates], mask_out float64 [n_gates].
+ * With doppler_scheme 1 or 2, rvel float64 [n_gates] receives doppler_sz.py:26
+ * (get_doppler_velocity); az_sub [n_sub] is GH_pt[0] of each sub-beam. */
+int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates, const float *values,
+                                const float *elev, const double *mask, const double *weight,
+                                const double *az_sub, float *obs, double *mask_out, double *rvel);
+
+/* ---- drop-in replacements of the reference's SWIG/C symbols --------------------------- */
+/* interpolation/interpolation_c.c:8,12 -- identical signature; runs on device 0 through a
+ * process-wide ctx (the model arrays are uploaded on every call, as SWIG converts them on
+ * every call in the reference, interpolation_c_wrap.c:3693-3762). */
+float *get_all_radar_pts(float *output, int len, float *coords_rad_pts, int crp_x, int crp_y,
+                         float *radar_heights, int rh_x, float *model_data, int md_x, int md_y, int md_z,
+                         float *model_heights, int mh_x, int mh_y, int mh_z,
+                         float *llc_cosmo, int llc_cosmo_x, float *res_cosmo, int res_cosmo_x);
+
+/* doppler/doppler_c.c:9,11 -- identical signature (three classes, stride 3). */
+float *get_refl(float *refl, int len, float *Da, int len_D_bins_x, int o2, float *Db, int o3, int o4,
+                float *D, int o5, int o6, float *rcs, int o8, int o9, float *N0, int o10,
+                float *mu, int o11, float *lambda, int o12, float *nu, int o13,
+                float *step_D, int o14, float *Dmin, int o15);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSMOPOL_H */

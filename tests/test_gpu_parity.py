@@ -1,0 +1,262 @@
+"""GPU: the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Tolerances (stated by the task): ZH / ZDR within 0.01 dB, KDP within 1e-3 deg/km, linear
+observables within 1e-5 relative, gate / level indexing bit-exact.  The f32 interpolation is
+compared bit for bit."""
+import numpy as np
+import pytest
+
+from cosmo_pol_amd import _lib, engine, synthetic as syn
+from cosmo_pol_amd.lut import Lookup_table
+from oracle import cosmo_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+OBS = _lib.OBS_NAMES
+
+
+def make_engine(conf, n_e=util.LUT_NE, n_t=util.LUT_NT):
+    eng = engine.Engine(conf, device=0)
+    tabs = util.synthetic_lut_arrays(conf['microphysics']['scheme'], conf['radar']['frequency'], n_e, n_t)
+    eng.upload_luts({h: Lookup_table.from_arrays(*t) for h, t in tabs.items()})
+    return eng
+
+
+def check_obs(obs, want, tag, rtol=1e-5, res_km=0.5):
+    """want: dict name -> f32 array (oracle or golden)."""
+    for i, n in enumerate(OBS):
+        w = np.asarray(want[n])
+        g = obs[i]
+        assert np.array_equal(np.isnan(g), np.isnan(w)), "%s %s: NaN pattern" % (tag, n)
+        ok = ~np.isnan(w)
+        if n in ('ZH', 'ZV', 'ZDR'):
+            db = np.abs(10 * np.log10(g[ok].astype(np.float64) / w[ok].astype(np.float64)))
+            assert db.max() < 0.01, "%s %s: %.3e dB" % (tag, n, db.max())
+        if n == 'KDP':
+            assert np.abs(g[ok] - w[ok]).max() < 1e-3, (tag, n)
+        scale = np.abs(w[ok]).astype(np.float64)
+        atol = 1e-5 * (np.nanmax(np.abs(np.asarray(want['KDP'], dtype=np.float64)), initial=0.) + 1e-30) \
+            if n in ('KDP', 'PHIDP', 'DELTA_HV') else 0.
+        if n == 'PHIDP':
+            # the reference accumulates PHIDP sequentially in float32 (np.cumsum); the GPU scans in
+            # float64.  The difference is the reference's own accumulation error, bounded by a few
+            # float32 ulps of the magnitude its accumulator has seen.
+            k = np.nan_to_num(np.asarray(want['KDP'], dtype=np.float64))
+            atol = atol + 4e-6 * np.cumsum(np.abs(2 * k))[ok] * res_km
+        err = np.abs(g[ok].astype(np.float64) - w[ok]) - rtol * scale - atol
+        assert err.max() <= 0, "%s %s: rel err %.3e at %d" % (
+            tag, n, np.max(np.abs(g[ok] - w[ok]) / (scale + 1e-300)), np.argmax(err))
+
+
+def beams_to_arrays(beams):
+    vals = {k: np.stack([b['values'][k] for b in beams]) for k in beams[0]['values']}
+    return (vals, np.stack([b['elev'] for b in beams]), np.stack([b['mask'] for b in beams]),
+            [b['GH_weight'] for b in beams], [b['GH_pt'][0] for b in beams])
+
+
+@pytest.mark.parametrize('name', ['obs_1mom_b1', 'obs_1mom_b9', 'obs_2mom_b9', 'obs_2mom_b3_x'])
+def test_observables_vs_golden(name):
+    """cpol_observables_from_beams == the reference's get_radar_observables (golden)."""
+    g = util.golden(name)
+    conf = util.cfg_from_meta(g['meta'], doppler={'scheme': 0})
+    eng = make_engine(conf)
+    beams = util.beams_from_golden(g)
+    obs, mask, _ = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    check_obs(obs, {n: g['out_' + n] for n in OBS}, name, res_km=float(g['meta'][5]) / 1000.)
+    np.testing.assert_array_equal(mask, g['out_mask'])
+
+
+@pytest.mark.parametrize('scheme,n_gates,n_sub,att', [(1, 667, 1, 1), (1, 667, 9, 1), (2, 500, 9, 1), (2, 300, 27, 0),
+                                                      (2, 1, 1, 1), (2, 65, 3, 1)])
+def test_observables_vs_oracle(scheme, n_gates, n_sub, att):
+    conf = O.make_config(microphysics={'scheme': scheme}, attenuation={'correction': att}, doppler={'scheme': 1},
+                         radar={'radial_resolution': 75. if scheme == 1 else 500., 'frequency': 5.6})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(n_gates, n_sub, scheme, seed=100 + n_gates, res=conf['radar']['radial_resolution'],
+                                nan_tail=min(7, n_gates // 3), below_head=min(2, n_gates // 4))
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    luts = util.oracle_luts(scheme, 5.6)
+    with np.errstate(all='ignore'):
+        want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf)
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
+    check_obs(obs, want.values, 'oracle', res_km=conf['radar']['radial_resolution'] / 1000.)
+    np.testing.assert_array_equal(mask, want.mask)
+    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+
+
+def test_observables_all_invalid():
+    """No hydrometeors anywhere: every observable is NaN, PHIDP is 0 (nan_cumsum)."""
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': 0})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(40, 3, 1, seed=3)
+    for b in beams:
+        for k in ('QR_v', 'QS_v', 'QG_v'):
+            b['values'][k][:] = 0
+    obs, mask, _ = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(beams), util.oracle_luts(1, 5.6), conf)
+    for i, n in enumerate(OBS):
+        np.testing.assert_array_equal(np.isnan(obs[i]), np.isnan(want.values[n]))
+    np.testing.assert_array_equal(obs[OBS.index('PHIDP')], want.values['PHIDP'])
+
+
+def small_model(scheme=2):
+    return syn.synthetic_model(nz=12, ny=40, nx=48, scheme=scheme, seed=99, llc=(-1.0, -0.8), res=(0.05, 0.04), ztop=9000.)
+
+
+def test_interp_points_bit_exact():
+    g = util.golden('interp')
+    m = small_model()
+    conf = O.make_config(microphysics={'scheme': 2})
+    eng = engine.Engine(conf, device=0)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    out = eng.ctx.interp_points(g['coords'], g['H'])
+    names = list(m['fields'].keys())
+    for name in ('T', 'QR_v', 'U', 'QNS_v'):
+        got, want = out[names.index(name)], g['out_' + name]
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_array_equal(got[ok].view(np.int32), want[ok].view(np.int32))
+    # every variable against the C restatement on fresh random points
+    rng = np.random.default_rng(8)
+    n = 5000
+    coords = np.empty((n, 2), dtype='float32')
+    coords[:, 0] = -0.8 + 0.04 * rng.uniform(0, 38.99, n)
+    coords[:, 1] = -1.0 + 0.05 * rng.uniform(0, 46.99, n)
+    H = rng.uniform(100., 9500., n).astype('float32')
+    out = eng.ctx.interp_points(coords, H)
+    llc = np.array([-1.0, -0.8], dtype='float32')
+    res = np.array([0.05, 0.04], dtype='float32')
+    for i, name in enumerate(names):
+        want = O.interp_c(coords, H, m['fields'][name], m['zlev'], llc, res)
+        np.testing.assert_array_equal(np.isnan(out[i]), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_array_equal(out[i][ok].view(np.int32), want[ok].view(np.int32))
+
+
+def test_get_all_radar_pts_dropin():
+    """The reference's C symbol, same signature, served by the GPU."""
+    import ctypes as C
+    g = util.golden('interp')
+    m = small_model()
+    lib = _lib.load()
+    n = len(g['H'])
+    for name in ('T', 'QNS_v'):
+        data = np.ascontiguousarray(m['fields'][name])
+        out = np.zeros(n, dtype='float32')
+        coords = np.ascontiguousarray(g['coords'])
+        H = np.ascontiguousarray(g['H'])
+        llc, res = np.ascontiguousarray(g['llc']), np.ascontiguousarray(g['res'])
+        r = lib.get_all_radar_pts(_lib.fptr(out), n, _lib.fptr(coords), n, 2, _lib.fptr(H), n, _lib.fptr(data), 12, 40, 48,
+                                  _lib.fptr(m['zlev']), 12, 40, 48, _lib.fptr(llc), 2, _lib.fptr(res), 2)
+        assert r
+        want = g['out_' + name]
+        np.testing.assert_array_equal(np.isnan(out), np.isnan(want))
+        ok = ~np.isnan(want)
+        np.testing.assert_array_equal(out[ok].view(np.int32), want[ok].view(np.int32))
+
+
+def test_get_refl_dropin():
+    g = util.golden('get_refl')
+    lib = _lib.load()
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    Da, Db, D, rcs = f(g['Da']), f(g['Db']), f(g['D']), f(g['rcs'])
+    N0, mu, lam, nu, step, dmin = f(g['N0']), f(g['mu']), f(g['lam']), f(g['nu']), f(g['step']), f(g['Dmin'])
+    out = np.zeros(len(g['out']), dtype=np.float32)
+    p = _lib.fptr
+    r = lib.get_refl(p(out), len(out), p(Da), Da.shape[0], 3, p(Db), Db.shape[0], 3, p(D), 1024, 3, p(rcs), 1024, 3,
+                     p(N0), 3, p(mu), 3, p(lam), 3, p(nu), 3, p(step), 3, p(dmin), 3)
+    assert r
+    np.testing.assert_allclose(out, g['out'], rtol=2e-6, atol=0)
+
+
+def pipeline_conf(scheme, nh, nv, res=500., rng=20000., dscheme=1):
+    return O.make_config(microphysics={'scheme': scheme}, doppler={'scheme': dscheme},
+                         radar={'coords': [46.0, 8.5, 1500.], 'radial_resolution': res, 'range': rng,
+                                'frequency': 5.6, '3dB_beamwidth': 1.0},
+                         integration={'scheme': 1, 'nh_GH': nh, 'nv_GH': nv, 'weight_threshold': 1.})
+
+
+def pipeline_model(scheme):
+    # rotated pole chosen so that the radar sits near the middle of the small grid
+    m = syn.synthetic_model(nz=16, ny=60, nx=64, scheme=scheme, seed=5, llc=(-1.6, -1.5), res=(0.05, 0.05),
+                            pole=(-44.0, 8.5), ztop=12000.)
+    return m
+
+
+def oracle_model_vars(m):
+    attrs = {'z-levels': m['zlev'], 'proj_info': m['proj_info'], 'resolution': m['resolution']}
+    return {n: O.ModelVar(a, attrs) for n, a in m['fields'].items()}
+
+
+def test_geolocate_vs_oracle():
+    conf = pipeline_conf(2, 3, 3)
+    m = pipeline_model(2)
+    eng = engine.Engine(conf, device=0)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    az_off, el_off, w = eng.set_gauss_hermite()
+    az = np.array([0., 33.3, 181.0, 359.5])
+    el = np.array([1.0, 5.5, 20.0, 89.0])
+    geo = eng.ctx.geolocate(az, el)
+    rr = O.radar_ranges(conf)
+    p = m['proj_info']
+    n_bad = 0
+    for r in range(len(az)):
+        for b in range(len(w)):
+            S, H, E = O.ref_4_3(rr, el_off[b] + el[r], conf['radar']['coords'])
+            for got, want in ((geo['dist'][r, b], S), (geo['height'][r, b], H), (geo['elev'][r, b], E)):
+                d = np.abs(got.view(np.int32) - want.view(np.int32))
+                assert d.max() <= 1
+                n_bad += int((d != 0).sum())
+            lon, lat = O.geod_fwd(conf['radar']['coords'][1], conf['radar']['coords'][0], az_off[b] + az[r],
+                                  geo['dist'][r, b].astype(np.float64))
+            np.testing.assert_allclose(geo['lat'][r, b], lat, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(geo['lon'][r, b], lon, rtol=0, atol=1e-12)
+            rot = O.wgs_to_rotated(geo['lat'][r, b], geo['lon'][r, b], p['Latitude_of_southern_pole'],
+                                   p['Longitude_of_southern_pole']).astype('float32')
+            d = np.abs(geo['coords'][r, b].view(np.int32) - rot.view(np.int32))
+            assert d.max() <= 1
+            n_bad += int((d != 0).sum())
+    # float64 libm differences may flip a float32 rounding now and then, never more
+    assert n_bad <= 0.001 * geo['dist'].size * 5
+
+
+@pytest.mark.parametrize('scheme,nh,nv', [(1, 1, 1), (2, 3, 3)])
+def test_run_rays_vs_oracle(scheme, nh, nv):
+    """Whole path (get_profiles_GH -> get_doppler_velocity -> get_radar_observables) for a few rays."""
+    conf = pipeline_conf(scheme, nh, nv)
+    m = pipeline_model(scheme)
+    eng = make_engine(conf)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    eng.set_gauss_hermite()
+    az = np.array([10., 100., 200., 300., 45.])
+    el = np.array([1.0, 3.0, 8.0, 15.0, 40.0])
+    out = eng.ctx.run_rays(az, el)
+    assert (out['ray_status'] == 0).all()
+    luts = util.oracle_luts(scheme, 5.6)
+    dic = oracle_model_vars(m)
+    for r in range(len(az)):
+        with np.errstate(all='ignore'):
+            beams = O.get_profiles_GH(dic, az[r], el[r], conf)
+            want_v = O.get_doppler_velocity(beams, luts, conf)
+            want = O.get_radar_observables(beams, luts, conf)
+        check_obs(out['obs'][:, r], want.values, 'ray %d' % r)
+        np.testing.assert_array_equal(out['mask'][r], want.mask)
+        util.assert_close(out['rvel'][r], want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+        np.testing.assert_array_equal(out['dist'][r], want.dist_profile)
+        np.testing.assert_array_equal(out['height'][r], want.heights_profile)
+        np.testing.assert_allclose(out['lat'][r], want.lats_profile, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(out['lon'][r], want.lons_profile, rtol=0, atol=1e-12)
+
+
+def test_run_rays_out_of_domain():
+    conf = pipeline_conf(1, 1, 1, rng=400000.)
+    m = pipeline_model(1)
+    eng = make_engine(conf)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    eng.set_gauss_hermite()
+    with pytest.raises(IndexError):
+        eng.ctx.run_rays(np.array([90.]), np.array([1.0]))
+    out = eng.ctx.run_rays(np.array([90.]), np.array([1.0]), raise_on_domain=False)
+    assert out['ray_status'][0] == _lib.ERR_DOMAIN
