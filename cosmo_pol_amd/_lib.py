@@ -54,7 +54,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_set_config', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -78,6 +78,9 @@ def load():
     lib.cpol_stream.argtypes = [vp]
     lib.cpol_stream.restype = vp
     lib.cpol_synchronize.argtypes = [vp]
+    lib.cpol_timing_enable.argtypes = [vp, C.c_int]
+    lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p]
+    lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
                                       c_float_p, c_float_p, c_float_p, c_double_p]
@@ -155,6 +158,22 @@ class Context(object):
 
     def synchronize(self):
         self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
+
+    STAGES = ['geom', 'interp', 'prep_sort', 'integrate', 'observables']
+
+    def timing_enable(self, on=True):
+        self._check(self.lib.cpol_timing_enable(self.h, int(on)), 'cpol_timing_enable')
+
+    def timing_read(self):
+        ms = (C.c_double * 5)()
+        nl = (C.c_long * 5)()
+        vu = C.c_double()
+        self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu)), 'cpol_timing_read')
+        return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
+                'valid_units': vu.value}
+
+    def set_batch_units(self, n):
+        self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')
 
     # -- state ---------------------------------------------------------------------
     def set_config(self, **kw):
@@ -237,10 +256,10 @@ class Context(object):
             self._check(ERR_DOMAIN, 'cpol_run_rays')
         return out
 
-    def run_rays_dev(self, az_ptr, el_ptr, n_rays):
+    def run_rays_dev(self, az_ptr, el_ptr, n_rays, outputs=None):
         """Device-resident variant: az/el may be host or device addresses; returns the struct of
         device pointers (valid until the next call on this context)."""
-        o = CpolOutputs()
+        o = outputs if outputs is not None else CpolOutputs()
         rc = self.lib.cpol_run_rays_dev(self.h, int(n_rays), int(az_ptr), int(el_ptr), C.byref(o))
         self._check(rc, 'cpol_run_rays_dev')
         return o

@@ -22,6 +22,82 @@ static int ensure(cpol_ctx *ctx, cpol_ctx::Buf &b, size_t bytes)
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != CPOL_OK) return rc_; } while (0)
 
+// ---- stage timing -------------------------------------------------------------------
+static hipEvent_t next_event(cpol_ctx *ctx)
+{
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_pool[ctx->ev_used++];
+}
+
+struct StageTimer {
+    cpol_ctx *ctx; int stage; hipEvent_t a = nullptr;
+    StageTimer(cpol_ctx *c, int st) : ctx(c), stage(st)
+    {
+        if (ctx->timing && (a = next_event(ctx))) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~StageTimer()
+    {
+        if (!a) return;
+        hipEvent_t b = next_event(ctx);
+        if (!b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->spans.push_back({stage, a, b});
+    }
+};
+
+static void timing_collect(cpol_ctx *ctx)
+{
+    for (auto &sp : ctx->spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            ctx->stage_ms[sp.stage] += ms;
+            ctx->stage_launches[sp.stage] += 1;
+        }
+    }
+    ctx->spans.clear();
+    ctx->ev_used = 0;
+    for (size_t i = 0; i < ctx->valid_used; i++) ctx->valid_units += ctx->valid_host[i];
+    ctx->valid_used = 0;
+}
+
+extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    timing_collect(ctx);
+    ctx->timing = on != 0;
+    for (int i = 0; i < CPOL_N_STAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_launches[i] = 0; }
+    ctx->valid_units = 0;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_launches[CPOL_N_STAGES],
+                                double *valid_units)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    timing_collect(ctx);
+    for (int i = 0; i < CPOL_N_STAGES; i++) {
+        if (stage_ms) stage_ms[i] = ctx->stage_ms[i];
+        if (stage_launches) stage_launches[i] = ctx->stage_launches[i];
+    }
+    if (valid_units) *valid_units = ctx->valid_units;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_set_batch_units(cpol_ctx *ctx, long max_units)
+{
+    if (!ctx || max_units < 1) return CPOL_ERR_ARG;
+    ctx->max_batch_units = (size_t)max_units;
+    return CPOL_OK;
+}
+
 static int fail(cpol_ctx *ctx, int code, const char *msg)
 {
     if (ctx) ctx->err = msg;
@@ -58,6 +134,8 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
         if (l.xmu) hipFree(l.xmu);
         if (l.d_axis) hipFree(l.d_axis);
     }
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    if (ctx->valid_host) hipHostFree(ctx->valid_host);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return CPOL_OK;
@@ -70,6 +148,7 @@ extern "C" int cpol_synchronize(cpol_ctx *ctx)
 {
     if (!ctx) return CPOL_ERR_ARG;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    timing_collect(ctx);
     return CPOL_OK;
 }
 
@@ -153,7 +232,6 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
     HIPCHK(ctx, hipMalloc((void **)&L.xq, 1024 * sizeof(float)));
     HIPCHK(ctx, hipMalloc((void **)&L.xmu, 1024 * sizeof(float)));
     HIPCHK(ctx, hipMalloc((void **)&L.d_axis, 1024 * sizeof(float)));
-    HIPCHK(ctx, hipMemcpy(L.table, lut->table, nt * sizeof(float), hipMemcpyDefault));
     std::vector<float> dax(1024), xq(1024), xmu(1024);
     HIPCHK(ctx, hipMemcpy(dax.data(), lut->d_axis, 1024 * sizeof(float), hipMemcpyDefault));
     for (int d = 0; d < 1024; d++) {
@@ -161,6 +239,22 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
         int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
         xq[(qd * 4 + kk) * 4 + s4] = (float)pow((double)dax[d], psd->nu);
         xmu[d] = (float)pow((double)dax[d], psd->mu);
+    }
+    {
+        // permuted, D^mu-weighted image of every (e, t) slice: see k_integrate
+        std::vector<float> host(nt), img(nt);
+        HIPCHK(ctx, hipMemcpy(host.data(), lut->table, nt * sizeof(float), hipMemcpyDefault));
+        const size_t nslice = (size_t)lut->n_e * lut->n_t;
+        for (size_t sl = 0; sl < nslice; sl++) {
+            const float *src = host.data() + sl * 1024 * CPOL_N_SZ;
+            float *dst = img.data() + sl * 1024 * CPOL_N_SZ;
+            for (int d = 0; d < 1024; d++) {
+                int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
+                for (int j = 0; j < CPOL_N_SZ; j++)
+                    dst[((qd * 48 + kk * 12 + j) << 2) + s4] = src[d * CPOL_N_SZ + j] * xmu[d];
+            }
+        }
+        HIPCHK(ctx, hipMemcpy(L.table, img.data(), nt * sizeof(float), hipMemcpyHostToDevice));
     }
     HIPCHK(ctx, hipMemcpy(L.xq, xq.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(L.xmu, xmu.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
@@ -257,16 +351,35 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->b_hist, (size_t)(4 * (nb + 1)) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
     int *hist = (int *)ctx->b_hist.p, *offs = hist + (nb + 1), *cursor = offs + (nb + 1), *chunk_off = cursor + (nb + 1);
+    {
+    StageTimer t_(ctx, CPOL_ST_PREP_SORT);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)(nb + 1) * sizeof(int), ctx->stream));
     launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme,
                 (int *)ctx->b_key.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, hist, offs, cursor, chunk_off);
     launch_scatter(ctx->stream, nslots, (const int *)ctx->b_key.p, cursor, (int *)ctx->b_sorted.p);
+    }
+    if (ctx->timing) {
+        // number of valid units of this batch (offs[nb]) for the work counters
+        if (ctx->valid_used == ctx->valid_cap) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            timing_collect(ctx);
+            if (!ctx->valid_host) {
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->valid_host, 4096 * sizeof(int), hipHostMallocDefault));
+                ctx->valid_cap = 4096;
+            }
+        }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->valid_host + ctx->valid_used++, offs + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
     long max_chunks = (nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb;
+    {
+    StageTimer t_(ctx, CPOL_ST_INTEGRATE);
     launch_integrate(ctx->stream, ct, max_chunks, nb, offs, chunk_off, (const int *)ctx->b_sorted.p,
                      (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
+    }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
+    StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
     launch_observables(ctx->stream, op, nr, nu, (const int *)ctx->b_key.p, (const double *)ctx->b_coef.p,
                        (const float *)ctx->b_psd.p, mask, wsub, (const double *)ctx->b_vr.p, obs, obs_plane, ray0,
                        mask_out, rvel_out);
@@ -329,13 +442,13 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
     TRY(ensure(ctx, ctx->b_az, n_rays * sizeof(double)));
     TRY(ensure(ctx, ctx->b_el, n_rays * sizeof(double)));
     TRY(ensure(ctx, ctx->b_status, n_rays * sizeof(int)));
-    TRY(ensure(ctx, ctx->o_obs, (size_t)CPOL_N_OBS * RG * sizeof(float)));
-    TRY(ensure(ctx, ctx->o_rvel, RG * sizeof(double)));
-    TRY(ensure(ctx, ctx->o_mask, RG * sizeof(double)));
-    TRY(ensure(ctx, ctx->o_lat, RG * sizeof(double)));
-    TRY(ensure(ctx, ctx->o_lon, RG * sizeof(double)));
-    TRY(ensure(ctx, ctx->o_dist, RG * sizeof(float)));
-    TRY(ensure(ctx, ctx->o_height, RG * sizeof(float)));
+    if (!out->obs) { TRY(ensure(ctx, ctx->o_obs, (size_t)CPOL_N_OBS * RG * sizeof(float))); out->obs = (float *)ctx->o_obs.p; }
+    if (!out->rvel) { TRY(ensure(ctx, ctx->o_rvel, RG * sizeof(double))); out->rvel = (double *)ctx->o_rvel.p; }
+    if (!out->mask) { TRY(ensure(ctx, ctx->o_mask, RG * sizeof(double))); out->mask = (double *)ctx->o_mask.p; }
+    if (!out->lat) { TRY(ensure(ctx, ctx->o_lat, RG * sizeof(double))); out->lat = (double *)ctx->o_lat.p; }
+    if (!out->lon) { TRY(ensure(ctx, ctx->o_lon, RG * sizeof(double))); out->lon = (double *)ctx->o_lon.p; }
+    if (!out->dist) { TRY(ensure(ctx, ctx->o_dist, RG * sizeof(float))); out->dist = (float *)ctx->o_dist.p; }
+    if (!out->height) { TRY(ensure(ctx, ctx->o_height, RG * sizeof(float))); out->height = (float *)ctx->o_height.p; }
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->b_status.p, 0, n_rays * sizeof(int), ctx->stream));
@@ -356,26 +469,30 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
     for (int r0 = 0; r0 < n_rays; r0 += rays_per_batch) {
         int nr = n_rays - r0 < rays_per_batch ? n_rays - r0 : rays_per_batch;
         long nu = (long)nr * per_ray;
-        launch_geom(ctx->stream, gp, nr, (const double *)ctx->b_az.p + r0, (const double *)ctx->b_el.p + r0,
-                    ctx->quad_dev, (double *)ctx->b_line.p, (float *)ctx->b_S.p, (float *)ctx->b_H.p,
-                    (float *)ctx->b_E.p, (double *)ctx->b_lat.p, (double *)ctx->b_lon.p, (float *)ctx->b_coords.p,
-                    (double *)ctx->b_phi.p, mv, (int *)ctx->b_status.p + r0);
-        launch_interp(ctx->stream, mv, nu, (const float *)ctx->b_coords.p, (const float *)ctx->b_H.p,
-                      (float *)ctx->b_vals.p, nu_max, (signed char *)ctx->b_mask.p, nullptr);
+        {
+            StageTimer t_(ctx, CPOL_ST_GEOM);
+            launch_geom(ctx->stream, gp, nr, (const double *)ctx->b_az.p + r0, (const double *)ctx->b_el.p + r0,
+                        ctx->quad_dev, (double *)ctx->b_line.p, (float *)ctx->b_S.p, (float *)ctx->b_H.p,
+                        (float *)ctx->b_E.p, (double *)ctx->b_lat.p, (double *)ctx->b_lon.p, (float *)ctx->b_coords.p,
+                        (double *)ctx->b_phi.p, mv, (int *)ctx->b_status.p + r0);
+            launch_gather_central(ctx->stream, nr, B, G, (const float *)ctx->b_S.p, (const float *)ctx->b_H.p,
+                                  (const double *)ctx->b_lat.p, (const double *)ctx->b_lon.p, out->dist,
+                                  out->height, out->lat, out->lon, r0);
+        }
+        {
+            StageTimer t_(ctx, CPOL_ST_INTERP);
+            launch_interp(ctx->stream, mv, nu, (const float *)ctx->b_coords.p, (const float *)ctx->b_H.p,
+                          (float *)ctx->b_vals.p, nu_max, (signed char *)ctx->b_mask.p, nullptr);
+        }
         TRY(run_physics(ctx, ct, nr, B, G, (const float *)ctx->b_vals.p, nu_max, (const float *)ctx->b_E.p,
                         (const signed char *)ctx->b_mask.p, wsub, (const double *)ctx->b_phi.p,
-                        (float *)ctx->o_obs.p, RG, r0, (double *)ctx->o_mask.p, (double *)ctx->o_rvel.p));
-        launch_gather_central(ctx->stream, nr, B, G, (const float *)ctx->b_S.p, (const float *)ctx->b_H.p,
-                              (const double *)ctx->b_lat.p, (const double *)ctx->b_lon.p, (float *)ctx->o_dist.p,
-                              (float *)ctx->o_height.p, (double *)ctx->o_lat.p, (double *)ctx->o_lon.p, r0);
+                        out->obs, RG, r0, out->mask, out->rvel));
     }
     HIPCHK(ctx, hipGetLastError());
-    out->obs = (float *)ctx->o_obs.p;
-    out->rvel = ctx->cfg.doppler_scheme ? (double *)ctx->o_rvel.p : nullptr;
-    out->mask = (double *)ctx->o_mask.p;
-    out->lat = (double *)ctx->o_lat.p; out->lon = (double *)ctx->o_lon.p;
-    out->dist = (float *)ctx->o_dist.p; out->height = (float *)ctx->o_height.p;
-    out->ray_status = (int *)ctx->b_status.p;
+    if (!ctx->cfg.doppler_scheme) out->rvel = nullptr;
+    if (out->ray_status) {
+        HIPCHK(ctx, hipMemcpyAsync(out->ray_status, ctx->b_status.p, n_rays * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    } else out->ray_status = (int *)ctx->b_status.p;
     return CPOL_OK;
 }
 
@@ -384,6 +501,7 @@ extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, c
 {
     if (!host) return CPOL_ERR_ARG;
     cpol_outputs d;
+    memset(&d, 0, sizeof(d));
     TRY(cpol_run_rays_dev(ctx, n_rays, azimuth, elevation, &d));
     const size_t RG = (size_t)n_rays * ctx->cfg.n_gates;
     hipStream_t s = ctx->stream;
@@ -396,6 +514,7 @@ extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, c
     if (host->height) HIPCHK(ctx, hipMemcpyAsync(host->height, d.height, RG * sizeof(float), hipMemcpyDeviceToHost, s));
     if (host->ray_status) HIPCHK(ctx, hipMemcpyAsync(host->ray_status, d.ray_status, n_rays * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
+    timing_collect(ctx);
     return CPOL_OK;
 }
 

@@ -15,7 +15,7 @@ struct LutDev {
     int    n_e = 0, n_t = 0, n_d = 0;
     float  e_min = 0, e_step = 1, t_min = 0, t_step = 1;
     float  dD = 0;                 // D[1]-D[0] in float32 (scattering_sz.py:50)
-    float *table = nullptr;        // [n_e][n_t][n_d][12]
+    float *table = nullptr;        // [n_e][n_t] slices of 1024 x 12, permuted and pre-multiplied by D^mu (see k_integrate)
     float *xq = nullptr;           // D^nu, permuted for the integrate kernel's ds_read_b128
     float *xmu = nullptr;          // D^mu
     float *d_axis = nullptr;       // [n_d]
@@ -95,6 +95,17 @@ struct cpol_ctx {
         b_sorted, b_psd, b_vr, b_hist, b_stage, b_az, b_el, b_status,
         o_obs, o_rvel, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)8 << 20;     // (ray x sub-beam x gate) positions per batch
+    // optional stage timing (hipEvents on ctx->stream) and work counters
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { int stage; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double stage_ms[CPOL_N_STAGES] = {0};
+    long   stage_launches[CPOL_N_STAGES] = {0};
+    int   *valid_host = nullptr;                  // pinned: valid units of each batch
+    size_t valid_cap = 0, valid_used = 0;
+    double valid_units = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                  \

@@ -469,8 +469,8 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             psd_params(p, q, qn, T, &l, &n0);
             double l2 = l * 1.4426950408889634;            // exponent in base 2
             float hi = (float)l2;
-            float lo = (float)(l2 - (double)hi);
-            lam[(long)h * nu + u] = make_float2(hi, lo);
+            float c = (float)(-(l2 - (double)hi) * 0.6931471805599453);
+            lam[(long)h * nu + u] = make_float2(hi, c);
             coef[(long)h * nu + u] = n0 * (double)lv.dD * w;
         }
         if (live) key[(long)h * nu + u] = k;
@@ -585,31 +585,35 @@ void launch_scatter(hipStream_t s, long nslots, const int *key, int *cursor, int
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define INTEG_THREADS 256
-#define LDS_B_FLOATS (1024 * CPOL_N_COL)
+#define SLICE_FLOATS (1024 * CPOL_N_SZ)      // one (e, t) node of the permuted table
+#define LDS_ZERO SLICE_FLOATS                // 4 zero floats read by the lanes of columns 12..15
+#define LDS_X (SLICE_FLOATS + 4)
 
-__global__ __launch_bounds__(INTEG_THREADS, 2)
+// Table image (global and LDS alike), built once at upload (api.hip, permute_table):
+//   img[((q*48 + k*12 + j) * 4 + s] = sz[d][j] * D_d^mu   with d = 16 q + 4 s + k
+// i.e. for the quad q of four consecutive MFMA steps s = 0..3, the lane (k = lane >> 4,
+// j = lane & 15 < 12) finds its four B operands in one 16-byte word.
+__global__ __launch_bounds__(INTEG_THREADS, 3)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                  const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
 {
-    __shared__ __attribute__((aligned(16))) float lds[LDS_B_FLOATS + 1024];
-    float *ldsB = lds;                 // [64 quads][64 lanes][4 steps]
-    float *ldsX = lds + LDS_B_FLOATS;  // [64 quads][4 k][4 steps]
+    __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 4 + 1024];
 
     // XCD-aware chunk order: workgroups that share an XCD (blockIdx % 8) take consecutive
-    // chunks, i.e. mostly the same table slice, so the slice is fetched into one L2.
-    const int total = chunk_off[nb];
-    const unsigned nwg = gridDim.x, orig = blockIdx.x;
-    const unsigned q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+    // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2.
+    const unsigned total = (unsigned)chunk_off[nb];
+    const unsigned orig = blockIdx.x;
+    if (orig >= total) return;
+    const unsigned q8 = total / 8, r8 = total % 8, xcd = orig % 8;
     const unsigned cid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
-    if ((int)cid >= total) return;
 
-    // bucket of this chunk: last b with chunk_off[b] <= cid
+    // bucket of this chunk: last b with chunk_off[b] <= cid (empty buckets share their
+    // successor's offset, so the last one is the owner)
     int lo = 0, hi = nb;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (chunk_off[mid] <= (int)cid) lo = mid; else hi = mid;
     }
-    // buckets with zero chunks share chunk_off with their successor: take the last one
     const int bkt = lo;
     const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
     int cnt = offs[bkt + 1] - start;
@@ -621,36 +625,29 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const LutView lv = ct.lut[h];
     const int tid = threadIdx.x;
 
-    // ---- stage the slice: B'[d][k] = sz[d][k] * D_d^mu, permuted so that a lane's four
-    // consecutive MFMA steps are one 16-byte LDS read ----
+    // ---- stage the slice: straight 16-byte copy of the pre-permuted image ----
     {
-        const float4 *src = (const float4 *)(lv.table + ((long)(ie * lv.n_t + it) * lv.n_d) * CPOL_N_SZ);
-        for (int i = tid; i < 1024 * 3; i += INTEG_THREADS) {
-            float4 v = src[i];
-            int d = i / 3, k4 = (i % 3) * 4;
-            float m = lv.xmu[d];
-            int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
-            float *dst = ldsB + ((qd * 64 + kk * 16 + k4) * 4 + s4);
-            dst[0] = v.x * m; dst[4] = v.y * m; dst[8] = v.z * m; dst[12] = v.w * m;
-        }
-        for (int i = tid; i < 1024; i += INTEG_THREADS) {
-            int qd = i >> 4, s4 = (i >> 2) & 3, kk = i & 3;
-            float *dst = ldsB + ((qd * 64 + kk * 16 + 12) * 4 + s4);
-            dst[0] = 0.f; dst[4] = 0.f; dst[8] = 0.f; dst[12] = 0.f;
-            ldsX[i] = lv.xq[i];
-        }
+        const float4 *src = (const float4 *)(lv.table + (long)(ie * lv.n_t + it) * SLICE_FLOATS);
+        float4 *dst = (float4 *)lds;
+#pragma unroll
+        for (int i = 0; i < SLICE_FLOATS / 4 / INTEG_THREADS; i++) dst[tid + i * INTEG_THREADS] = src[tid + i * INTEG_THREADS];
+        ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
+        if (tid == 0) *(float4 *)(lds + LDS_ZERO) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
     const int ngroups = (cnt + 15) >> 4;
-    const float4 *B4 = (const float4 *)ldsB;
-    const float4 *X4 = (const float4 *)ldsX;
-    const float nln2 = -0.6931471805599453f;
+    const int kq = lane >> 4, j = lane & 15;
+    const float4 *B4 = (const float4 *)lds;
+    const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
+    // float4 index of this lane's operand word inside quad 0 (stride 48 per quad)
+    const int boff = j < 12 ? kq * 12 + j : -1;
 
     for (int g0 = wave * 2; g0 < ngroups; g0 += 8) {
         // two groups of 16 units per pass (two independent accumulators)
-        int ua = g0 * 16 + (lane & 15), ub = ua + 16;
+        int ua = g0 * 16 + j, ub = ua + 16;
+        // per unit: (hi, c) with exp(-lambda D^nu) = exp2(-hi x) * (1 + c x), x = D^nu
         float2 la = make_float2(0.f, 0.f), lb = la;
         if (ua < cnt) la = lam[sorted[start + ua]];
         if (ub < cnt) lb = lam[sorted[start + ub]];
@@ -659,18 +656,15 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
             for (int qd = qo; qd < qo + 8; qd++) {
-                float4 bq = B4[qd * 64 + lane];
-                float4 xq = X4[qd * 4 + (lane >> 4)];
+                float4 bq = B4[boff >= 0 ? qd * 48 + boff : LDS_ZERO / 4];
+                float4 xq = X4[qd * 4];
                 const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
                 const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
                     float x = xx[s4];
-                    float pa = la.x * x, pb = lb.x * x;
-                    float ra = fmaf(la.x, x, -pa), rb = fmaf(lb.x, x, -pb);
-                    ra = fmaf(la.y, x, ra); rb = fmaf(lb.y, x, rb);
-                    float ea = __builtin_amdgcn_exp2f(-pa), eb = __builtin_amdgcn_exp2f(-pb);
-                    float na = fmaf(ea, ra * nln2, ea), nb_ = fmaf(eb, rb * nln2, eb);
+                    float ea = __builtin_amdgcn_exp2f(-(la.x * x)), eb = __builtin_amdgcn_exp2f(-(lb.x * x));
+                    float na = fmaf(ea, la.y * x, ea), nb_ = fmaf(eb, lb.y * x, eb);
                     acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na, bb[s4], acca, 0, 0, 0);
                     accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_, bb[s4], accb, 0, 0, 0);
                 }
@@ -679,13 +673,14 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
         }
         // C/D layout: column = lane & 15 (component), row = (lane >> 4) * 4 + r (unit in group)
-        const int col = lane & 15;
+        if (j < CPOL_N_SZ) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int row = (lane >> 4) * 4 + r;
-            int u0 = g0 * 16 + row, u1 = u0 + 16;
-            if (u0 < cnt) psd_out[(long)sorted[start + u0] * CPOL_N_COL + col] = (float)da[r];
-            if (u1 < cnt) psd_out[(long)sorted[start + u1] * CPOL_N_COL + col] = (float)db[r];
+            for (int r = 0; r < 4; r++) {
+                int row = kq * 4 + r;
+                int u0 = g0 * 16 + row, u1 = u0 + 16;
+                if (u0 < cnt) psd_out[(long)sorted[start + u0] * CPOL_N_COL + j] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)sorted[start + u1] * CPOL_N_COL + j] = (float)db[r];
+            }
         }
     }
 }

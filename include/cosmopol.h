@@ -95,6 +95,21 @@ const char *cpol_last_error(cpol_ctx *ctx);
 void *cpol_stream(cpol_ctx *ctx);
 int  cpol_synchronize(cpol_ctx *ctx);
 
+/* ---- measurement -------------------------------------------------------------------- */
+/* Stage timing with HIP events recorded on the ctx stream around each group of kernels
+ * (no counterpart in the reference, which only has utilities/tictoc.py).  While enabled,
+ * every cpol_run_rays* / cpol_observables_from_beams call adds to the totals; read them
+ * after cpol_synchronize().  valid_units = number of (gate, sub-beam, class) units that
+ * went through the PSD integration, the quantity its arithmetic scales with. */
+#define CPOL_N_STAGES 5
+enum cpol_stage { CPOL_ST_GEOM = 0, CPOL_ST_INTERP, CPOL_ST_PREP_SORT, CPOL_ST_INTEGRATE, CPOL_ST_OBSERVABLES };
+int cpol_timing_enable(cpol_ctx *ctx, int on);          /* also resets the totals */
+int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_launches[CPOL_N_STAGES],
+                     double *valid_units);
+/* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
+ * workspace the library allocates (default 8 Mi positions, about 3.5 GB). */
+int cpol_set_batch_units(cpol_ctx *ctx, long max_units);
+
 /* ---- state -------------------------------------------------------------------------- */
 /* utilities/cfg.py CONFIG + constants.update() (radar_operator.py:39-40). */
 int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg);
@@ -128,8 +143,11 @@ int cpol_set_quadrature(cpol_ctx *ctx, int n_sub, const double *az_off, const do
  *   mask  float64 [n_rays][n_gates]               scattering_sz.py:144-151
  *   lat, lon float64, dist, height float32 [n_rays][n_gates]   central sub-beam geometry
  * ray_status int32 [n_rays]: CPOL_OK or CPOL_ERR_DOMAIN per ray.
- * cpol_run_rays copies to host buffers; cpol_run_rays_dev leaves results in ctx-owned
- * device buffers (valid until the next call) and returns their addresses. */
+ * cpol_run_rays copies to host buffers.  cpol_run_rays_dev works on device memory: members
+ * of dev_out that are non-NULL on entry are caller-owned device buffers and are filled in
+ * place; NULL members are served from ctx-owned buffers (valid until the next call) whose
+ * addresses are stored into dev_out.  Work is queued on the ctx stream; call
+ * cpol_synchronize() before reading. */
 typedef struct {
     float  *obs;
     double *rvel;
