@@ -209,6 +209,8 @@ static void fill_psd(PsdView &v, const cpol_psd &p)
     v.lambda_factor = p.lambda_factor; v.vel_factor = p.vel_factor; v.ntot_factor = p.ntot_factor;
     v.n0_fixed = p.n0_fixed; v.x_min = p.x_min; v.x_max = p.x_max; v.q_var = p.q_var; v.qn_var = p.qn_var;
     v.t_var = (p.t_var >= 0 && p.t_var < CPOL_V_COUNT) ? p.t_var : CPOL_V_T;
+    v.n0_unit = pow(1000., -(1 + p.mu));
+    v.lam_unit = pow(1000., -p.nu);
 }
 
 extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,
@@ -347,17 +349,21 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
     TRY(ensure(ctx, ctx->b_sorted, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->b_rank, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_psd, (size_t)nslots * CPOL_N_COL * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_hist, (size_t)(4 * (nb + 1)) * sizeof(int)));
+    TRY(ensure(ctx, ctx->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
-    int *hist = (int *)ctx->b_hist.p, *offs = hist + (nb + 1), *cursor = offs + (nb + 1), *chunk_off = cursor + (nb + 1);
+    int *hist = (int *)ctx->b_hist.p, *cursor = hist + CPOL_SORT_SHARDS * (nb + 1), *offs = cursor + CPOL_SORT_SHARDS * (nb + 1),
+        *chunk_off = offs + (nb + 1);
     {
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
-    HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)(nb + 1) * sizeof(int), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
     launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme,
-                (int *)ctx->b_key.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p, hist, (double *)ctx->b_vr.p);
+                (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p, hist,
+                (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, hist, offs, cursor, chunk_off);
-    launch_scatter(ctx->stream, nslots, (const int *)ctx->b_key.p, cursor, (int *)ctx->b_sorted.p);
+    launch_scatter(ctx->stream, nu, ct.n_cls, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, cursor,
+                   (int *)ctx->b_sorted.p);
     }
     if (ctx->timing) {
         // number of valid units of this batch (offs[nb]) for the work counters
@@ -413,7 +419,7 @@ static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)
     TRY(ensure(ctx, ctx->b_lon, nu * sizeof(double)));
     TRY(ensure(ctx, ctx->b_coords, nu * 2 * sizeof(float)));
     TRY(ensure(ctx, ctx->b_line, (size_t)nrb * 28 * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_phi, (size_t)nrb * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_phi, (size_t)nrb * 2 * sizeof(double)));
     return CPOL_OK;
 }
 
@@ -601,12 +607,16 @@ extern "C" int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_E.p, elev, nu * sizeof(float), hipMemcpyDefault, s));
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_mask.p, m8.data(), nu, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(ctx->t_a.p, weight, n_sub * sizeof(double), hipMemcpyDefault, s));
-    if (az_sub) HIPCHK(ctx, hipMemcpyAsync(ctx->t_b.p, az_sub, n_sub * sizeof(double), hipMemcpyDefault, s));
+    TRY(ensure(ctx, ctx->b_phi, (size_t)n_sub * 2 * sizeof(double)));
+    if (az_sub) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->t_b.p, az_sub, n_sub * sizeof(double), hipMemcpyDefault, s));
+        launch_sincos_deg(s, n_sub, (const double *)ctx->t_b.p, (double *)ctx->b_phi.p);
+    }
     HIPCHK(ctx, hipStreamSynchronize(s));      // m8 is a local buffer
     int save_sens = ctx->cfg.sensitivity_mode;
     ctx->cfg.sensitivity_mode = 0;             // get_radar_observables itself applies no cut
     int rc = run_physics(ctx, ct, 1, n_sub, n_gates, (const float *)ctx->b_vals.p, nu, (const float *)ctx->b_E.p,
-                         (const signed char *)ctx->b_mask.p, (const double *)ctx->t_a.p, (const double *)ctx->t_b.p,
+                         (const signed char *)ctx->b_mask.p, (const double *)ctx->t_a.p, (const double *)ctx->b_phi.p,
                          (float *)ctx->t_c.p, n_gates, 0, (double *)ctx->t_d.p, (double *)ctx->t_e.p);
     ctx->cfg.sensitivity_mode = save_sens;
     TRY(rc);

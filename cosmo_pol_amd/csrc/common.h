@@ -8,6 +8,7 @@
 
 #define CPOL_WAVE 64
 #define CPOL_CHUNK_UNITS 256      // units (gate x sub-beam x class) per integrate workgroup
+#define CPOL_SORT_SHARDS 16         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_N_COL 16             // MFMA N dimension: 12 scattering components + 4 spare columns
 
 struct LutDev {
@@ -36,6 +37,7 @@ struct PsdView {
     int    kind;
     double a, b, alpha, beta, mu, nu, lambda_factor, vel_factor, ntot_factor, n0_fixed, x_min, x_max;
     int    q_var, qn_var, t_var;
+    double n0_unit, lam_unit;      // 1000^-(1+mu), 1000^-nu (hydrometeors.py:149,151)
 };
 
 struct ClassTable {
@@ -92,7 +94,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     std::vector<Buf *> bufs;
     Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-        b_sorted, b_psd, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+        b_sorted, b_rank, b_psd, b_vr, b_hist, b_stage, b_az, b_el, b_status,
         o_obs, o_rvel, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)8 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
@@ -126,9 +128,11 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
                    float *vals, long plane, signed char *mask, float *raw_out);
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                  const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
-                 const double *phi, int doppler, int *key, float2 *lam, double *coef, int *hist, double *vr);
+                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, int *hist,
+                 double *vr);
+void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off);
-void launch_scatter(hipStream_t s, long nslots, const int *key, int *cursor, int *sorted);
+void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,

@@ -126,7 +126,10 @@ __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict_
     double azi1 = quad[b] + az[r];                       // pts_hor[i] + azimuth (interpolation.py:265)
     double el_b = quad[gp.n_sub + b] + el[r];            // pts_ver[j] + elevation
     double *L = line + (long)t * LINE_N;
-    phi[t] = azi1;
+    {   // azimuth of the sub-beam for the wind projection (doppler_sz.py:76)
+        double pr = azi1 * (M_PI / 180.0);
+        phi[2 * t] = sin(pr); phi[2 * t + 1] = cos(pr);
+    }
 
     const double f = 1.0 / 298.257223563, f1 = 1 - f, e2 = f * (2 - f), ep2 = e2 / (f1 * f1);
     const double n = f / (2 - f);
@@ -400,26 +403,30 @@ __device__ inline float fold_elev(float e)
     return e;
 }
 
+// x^y for x > 0 through exp(y log x): relative error ~ |y log x| * 2^-53, far below the
+// float32 resolution of every consumer, at about half the cost of pow().
+__device__ inline double powxy(double x, double y) { return exp(y * log(x)); }
+
 // lambda and N0 of one class at one gate (float64, float32 where the reference's
 // NumPy promotion keeps float32).  Returns false when Q is not usable.
 __device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, double *lam, double *n0)
 {
     if (p.kind == 0) {
-        *lam = pow(p.lambda_factor / (double)q, 1. / (4. + p.mu));
+        *lam = powxy(p.lambda_factor / (double)q, 1. / (4. + p.mu));
         *n0 = p.n0_fixed;
     } else if (p.kind == 1) {
         // exp through float64 so that subnormal float32 results are kept, as glibc's expf keeps them
         float n0f = 13.5f * (565000.0f * (float)exp((double)(-0.107f * (T - 273.15f)))) / 1000.f;
         float an0 = (float)p.a * n0f;
-        *lam = pow((double)an0 * p.lambda_factor / (double)q, 1. / (p.b + 1));
+        *lam = powxy((double)an0 * p.lambda_factor / (double)q, 1. / (p.b + 1));
         *n0 = (double)n0f;
     } else {
         float xm = q * 1.0f / (qn + 1.1920929e-07f);
         xm = fminf(fmaxf(xm, (float)p.x_min), (float)p.x_max);
-        double l = pow(p.lambda_factor * (double)xm, -p.nu / p.b);
-        double n = (p.nu / p.ntot_factor) * (double)qn * pow(l, (p.mu + 1) / p.nu);
-        *n0 = n * pow(1000., -(1 + p.mu));
-        *lam = l * pow(1000., -p.nu);
+        double l = powxy(p.lambda_factor * (double)xm, -p.nu / p.b);
+        double n = (p.nu / p.ntot_factor) * (double)qn * powxy(l, (p.mu + 1) / p.nu);
+        *n0 = n * p.n0_unit;
+        *lam = l * p.lam_unit;
     }
     return true;
 }
@@ -440,9 +447,9 @@ __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
 
 __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
                        const float *__restrict__ elev, const signed char *__restrict__ mask,
-                       const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi, int doppler,
-                       int *__restrict__ key, float2 *__restrict__ lam, double *__restrict__ coef,
-                       int *__restrict__ hist, double *__restrict__ vr)
+                       const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
+                       int *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
+                       double *__restrict__ coef, int *__restrict__ hist, double *__restrict__ vr)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -474,50 +481,72 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             coef[(long)h * nu + u] = n0 * (double)lv.dD * w;
         }
         if (live) key[(long)h * nu + u] = k;
+        // position of the unit inside its (bucket, shard) counter: one atomic per run of equal keys
         int hl, len;
         wave_run(k, lane, &hl, &len);
-        if (k >= 0 && hl == lane) atomicAdd(&hist[k], len);
+        int base = 0;
+        if (k >= 0 && hl == lane) base = atomicAdd(&hist[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))], len);
+        base = __shfl(base, hl);
+        if (k >= 0) rank[(long)h * nu + u] = base + (lane - hl);
     }
     if (doppler == 1 && live) {
         // doppler_sz.py:130-153 (closed-form PSD-weighted fall speed) and :75-87 (projection)
-        double vh = __builtin_nan(""), nn = __builtin_nan("");
+        double vh = 0., nn = 0.;            // nansum_arr: NaN counts as 0 (utilities.py:46-66)
         for (int h = 0; h < ct.n_cls; h++) {
             const PsdView &p = ct.dop[h];
             float q = vals[(long)p.q_var * plane + uu];
             float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
-            double l, n0, vi, ni;
-            float Tp = vals[(long)p.t_var * plane + uu];
-            psd_params(p, q, qn, Tp, &l, &n0);
-            if (q == 0.f) l = __builtin_nan("");
-            vi = p.vel_factor * n0 * p.alpha / p.nu * pow(l, -(p.beta + p.mu + 1) / p.nu);
-            if (p.kind == 2) ni = (double)qn;
-            else ni = p.ntot_factor * n0 / p.nu * pow(l, -(p.mu + 1) / p.nu);
-            // nansum_arr: NaN counts as 0 once anything was added (utilities.py:46-66)
-            vh = (vh != vh ? 0. : vh) + (vi != vi ? 0. : vi);
-            nn = (nn != nn ? 0. : nn) + (ni != ni ? 0. : ni);
+            if (q > 0.f) {
+                double l, n0, vi, ni;
+                float Tp = vals[(long)p.t_var * plane + uu];
+                psd_params(p, q, qn, Tp, &l, &n0);
+                double ll = log(l);
+                vi = p.vel_factor * n0 * p.alpha / p.nu * exp(ll * (-(p.beta + p.mu + 1) / p.nu));
+                if (p.kind == 2) ni = (double)qn;
+                else ni = p.ntot_factor * n0 / p.nu * exp(ll * (-(p.mu + 1) / p.nu));
+                vh += (vi != vi ? 0. : vi);
+                nn += (ni != ni ? 0. : ni);
+            } else if (p.kind == 2 && qn == qn) {
+                nn += (double)qn;             // lambda is NaN, N_int = ntot = QN (hydrometeors.py:77-78)
+            }
         }
         float rho = vals[(long)CPOL_V_RHO * plane + uu];
         float rho0 = vals[(long)CPOL_V_RHO * plane + rb * n_gates];
         float rc = sqrtf(rho / rho0);
         double vhyd = vh / nn * (double)rc;
         float th = e_raw * (float)(M_PI / 180.0);
-        double ph = phi[rb] * (M_PI / 180.0);
+        double sph = phi_sc[2 * rb], cph = phi_sc[2 * rb + 1];
         double U = vals[(long)CPOL_V_U * plane + uu], V = vals[(long)CPOL_V_V * plane + uu];
         double W = vals[(long)CPOL_V_W * plane + uu];
-        vr[u] = (U * sin(ph) + V * cos(ph)) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
+        vr[u] = (U * sph + V * cph) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
     }
+}
+
+__global__ void k_sincos_deg(int n, const double *__restrict__ deg, double *__restrict__ sc)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r = deg[i] * (M_PI / 180.0);
+    sc[2 * i] = sin(r); sc[2 * i + 1] = cos(r);
+}
+
+void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc)
+{
+    hipLaunchKernelGGL(k_sincos_deg, dim3((n + 63) / 64), dim3(64), 0, s, n, deg, sc);
 }
 
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                  const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
-                 const double *phi, int doppler, int *key, float2 *lam, double *coef, int *hist, double *vr)
+                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, int *hist,
+                 double *vr)
 {
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, ct, nu, n_gates, vals, plane,
-                       elev, mask, weight_per_sub, n_sub, phi, doppler, key, lam, coef, hist, vr);
+                       elev, mask, weight_per_sub, n_sub, phi_sc, doppler, key, rank, lam, coef, hist, vr);
 }
 
-// Exclusive scan of the bucket histogram (nb <= 8192) -> offsets, scatter cursors and
-// the chunk table of the integrate kernel.  One workgroup.
+// Exclusive scan of the sharded bucket histogram (nb <= 8192 buckets x CPOL_SORT_SHARDS
+// counters) -> bucket offsets, per-shard scatter cursors and the chunk table of the
+// integrate kernel.  One workgroup.
 __global__ void k_scan(int nb, const int *__restrict__ hist, int *__restrict__ offs, int *__restrict__ cursor,
                        int *__restrict__ chunk_off)
 {
@@ -527,7 +556,9 @@ __global__ void k_scan(int nb, const int *__restrict__ hist, int *__restrict__ o
     int a = 0, c = 0;
     for (int i = 0; i < per; i++) {
         int j = t * per + i;
-        int v = j < nb ? hist[j] : 0;
+        int v = 0;
+        if (j < nb)
+            for (int sh = 0; sh < CPOL_SORT_SHARDS; sh++) v += hist[j * CPOL_SORT_SHARDS + sh];
         a += v;
         c += (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
     }
@@ -543,8 +574,12 @@ __global__ void k_scan(int nb, const int *__restrict__ hist, int *__restrict__ o
     for (int i = 0; i < per; i++) {
         int j = t * per + i;
         if (j < nb) {
-            int v = hist[j];
-            offs[j] = ea; cursor[j] = ea; chunk_off[j] = eb;
+            offs[j] = ea; chunk_off[j] = eb;
+            int v = 0;
+            for (int sh = 0; sh < CPOL_SORT_SHARDS; sh++) {
+                cursor[j * CPOL_SORT_SHARDS + sh] = ea + v;
+                v += hist[j * CPOL_SORT_SHARDS + sh];
+            }
             ea += v;
             eb += (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
         }
@@ -557,22 +592,20 @@ void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nb, hist, offs, cursor, chunk_off);
 }
 
-__global__ void k_scatter(long nslots, const int *__restrict__ key, int *__restrict__ cursor, int *__restrict__ sorted)
+// Final position of every valid unit = start of its (bucket, shard) range + the rank k_prep drew.
+__global__ void k_scatter(long nu, const int *__restrict__ key, const int *__restrict__ rank,
+                          const int *__restrict__ cursor, int *__restrict__ sorted)
 {
-    long sidx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int lane = threadIdx.x & 63;
-    int k = sidx < nslots ? key[sidx] : -1;
-    int hl, len;
-    wave_run(k, lane, &hl, &len);
-    int base = 0;
-    if (k >= 0 && hl == lane) base = atomicAdd(&cursor[k], len);
-    base = __shfl(base, hl);
-    if (k >= 0) sorted[base + (lane - hl)] = (int)sidx;
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nu) return;
+    long slot = (long)blockIdx.y * nu + u;
+    int k = key[slot];
+    if (k >= 0) sorted[cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
 }
 
-void launch_scatter(hipStream_t s, long nslots, const int *key, int *cursor, int *sorted)
+void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, s, nslots, key, cursor, sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_cls), dim3(256), 0, s, nu, key, rank, cursor, sorted);
 }
 
 // =============================================================================
