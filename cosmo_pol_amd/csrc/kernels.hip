@@ -313,12 +313,21 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
                          float *__restrict__ vals, long plane, signed char *__restrict__ mask,
                          float *__restrict__ raw_out)
 {
+    // Phase A (one thread per point): grid position, terrain test, level search.
+    // Phase B (wave-cooperative): the 2 x nv values of a neighbour column are contiguous in
+    // memory, so 32 lanes fetch them with one coalesced access instead of 2 nv scattered ones.
+    // Phase C: results go through LDS so that every variable plane is written 64 points at a time.
+    __shared__ int s_base[4][4][64];
+    __shared__ float s_fz[4][4][64], s_hz[4][4][64], s_xy[4][4][64];
+    __shared__ int s_code[4][64];
+    __shared__ float s_out[4][16][65];
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
+    const bool live = u < n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float qnan = __builtin_nanf("");
-    float H = Hh[u];
-    float p0 = (coords[2 * u] - mv.llc1) / mv.res1;       // lat-like -> row
-    float p1 = (coords[2 * u + 1] - mv.llc0) / mv.res0;   // lon-like -> column
+    float H = live ? Hh[u] : 0.f;
+    float p0 = live ? (coords[2 * u] - mv.llc1) / mv.res1 : -1.f;       // lat-like -> row
+    float p1 = live ? (coords[2 * u + 1] - mv.llc0) / mv.res0 : -1.f;   // lon-like -> column
     int iy = (int)floorf(p0), ix = (int)floorf(p1);
     float x = fmodf(p0, 1.0f), y = fmodf(p1, 1.0f);
     float dx = 1.0f - x, dy = 1.0f - y;
@@ -336,44 +345,113 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
         float topo = dx * dy * t0 + x * t2 * dy + dx * t1 * y + x * y * t3;
         if (!(topo < H)) code = 1;
         else {
+            // the four column searches of interpolation_c.c:108-135 run in lockstep (same probes and
+            // decisions per column as the reference's loop; four loads in flight instead of one)
+            const float *col[4];
+            int hi_[4], lo_[4], res[4];
+            bool done[4];
+            bool above = false;
+#pragma unroll
             for (int j = 0; j < 4; j++) {
-                int idx = level_search(mv.zcol + cell[j] * nz, nz, H);
-                if (idx == -1) { code = -1; break; }
-                if (idx == -2) idx = nz - 3;
-                else if (idx == nz - 2) idx--;
-                c1[j] = idx;
+                col[j] = mv.zcol + cell[j] * nz;
+                float top = col[j][0];
+                float bot = (j == 0) ? t0 : (j == 1) ? t1 : (j == 2) ? t2 : t3;   // col[j][nz-1]
+                hi_[j] = 0; lo_[j] = nz - 1; res[j] = 0; done[j] = false;
+                if (H > top) { above = true; done[j] = true; }
+                else if (H < bot) { res[j] = -2; done[j] = true; }
+            }
+            if (above) code = -1;
+            else {
+                for (int itn = 0; itn < 32; itn++) {
+                    bool all = true;
+                    float v[4];
+                    int mid[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        mid[j] = (hi_[j] + lo_[j]) / 2;
+                        if (!done[j] && !(hi_[j] < lo_[j])) { res[j] = hi_[j]; done[j] = true; }
+                        v[j] = done[j] ? 0.f : col[j][mid[j]];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (!done[j]) {
+                            if (v[j] == H) { res[j] = mid[j]; done[j] = true; }
+                            else if (lo_[j] == mid[j] || hi_[j] == mid[j]) { res[j] = hi_[j]; done[j] = true; }
+                            else if (v[j] < H) lo_[j] = mid[j];
+                            else if (v[j] > H) hi_[j] = mid[j];
+                            else { res[j] = hi_[j]; done[j] = true; }   // NaN height
+                        }
+                        all = all && done[j];
+                    }
+                    if (all) break;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int idx = res[j];
+                    if (idx == -2) idx = nz - 3;
+                    else if (idx == nz - 2) idx--;
+                    c1[j] = idx;
+                }
             }
         }
     }
-    if (mask) mask[u] = (signed char)code;
+    if (mask && live) mask[u] = (signed char)code;
     const int nv = mv.nv;
-    if (code != 0) {
-        // raw_out keeps the reference's sentinels; vals gets NaN (interpolation.py:277)
-        for (int v = 0; v < nv; v++) {
-            if (raw_out) raw_out[(long)v * n + u] = code < 0 ? -9999.f : qnan;
-            if (vals) vals[(long)mv.var_of_slot[v] * plane + u] = qnan;
-        }
-        return;
-    }
-    float fz[4], hz[4];
-    const float *dp[4];
-    for (int j = 0; j < 4; j++) {
-        const float *zc = mv.zcol + cell[j] * nz + c1[j];
-        float za = zc[0], zb = zc[1];
-        fz[j] = za - zb;
-        hz[j] = H - zb;
-        dp[j] = mv.dcol + (cell[j] * nz + c1[j]) * nv;
-    }
-    for (int v = 0; v < nv; v++) {
-        float w[4];
+    s_code[wv][lane] = code;
+    s_xy[wv][0][lane] = x; s_xy[wv][1][lane] = y; s_xy[wv][2][lane] = dx; s_xy[wv][3][lane] = dy;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float va = dp[j][v], vb = dp[j][nv + v];
-            w[j] = vb - (vb - va) / fz[j] * hz[j];
+    for (int j = 0; j < 4; j++) {
+        float fzj = 1.f, hzj = 0.f;
+        int basej = 0;
+        if (code == 0) {
+            const float *zc = mv.zcol + cell[j] * nz + c1[j];
+            float za = zc[0], zb = zc[1];
+            fzj = za - zb;
+            hzj = H - zb;
+            basej = (int)(cell[j] * nz + c1[j]);
         }
-        float o = dx * dy * w[0] + x * w[2] * dy + dx * w[1] * y + x * y * w[3];
-        if (raw_out) raw_out[(long)v * n + u] = o;
-        if (vals) vals[(long)mv.var_of_slot[v] * plane + u] = o;
+        s_base[wv][j][lane] = basej; s_fz[wv][j][lane] = fzj; s_hz[wv][j][lane] = hzj;
+    }
+    __syncthreads();
+    {
+        const int sl = lane & 31, v = sl & 15, lev = sl >> 4;
+        const bool vact = v < nv;
+        for (int p8 = 0; p8 < 32; p8 += 8) {
+            // issue the 32 loads of eight point pairs before using any of them
+            float val[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int pos = 2 * (p8 + i) + (lane >> 5);
+                const bool ok = s_code[wv][pos] == 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    val[i][j] = 0.f;
+                    if (ok && vact) val[i][j] = mv.dcol[(long)s_base[wv][j][pos] * nv + lev * nv + v];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int pos = 2 * (p8 + i) + (lane >> 5);
+                float w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float vb = __shfl_down(val[i][j], 16);
+                    w[j] = vb - (vb - val[i][j]) / s_fz[wv][j][pos] * s_hz[wv][j][pos];
+                }
+                const float px = s_xy[wv][0][pos], py = s_xy[wv][1][pos], pdx = s_xy[wv][2][pos], pdy = s_xy[wv][3][pos];
+                float o = pdx * pdy * w[0] + px * w[2] * pdy + pdx * w[1] * py + px * py * w[3];
+                if (lev == 0 && vact) s_out[wv][v][pos] = o;
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        for (int v = 0; v < nv; v++) {
+            float o = s_out[wv][v][lane];
+            // raw_out keeps the reference's sentinels; vals gets NaN (interpolation.py:277)
+            if (raw_out) raw_out[(long)v * n + u] = code == 0 ? o : (code < 0 ? -9999.f : qnan);
+            if (vals) vals[(long)mv.var_of_slot[v] * plane + u] = code == 0 ? o : qnan;
+        }
     }
 }
 
@@ -476,8 +554,7 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             psd_params(p, q, qn, T, &l, &n0);
             double l2 = l * 1.4426950408889634;            // exponent in base 2
             float hi = (float)l2;
-            float c = (float)(-(l2 - (double)hi) * 0.6931471805599453);
-            lam[(long)h * nu + u] = make_float2(hi, c);
+            lam[(long)h * nu + u] = make_float2(hi, (float)(l2 - (double)hi));
             coef[(long)h * nu + u] = n0 * (double)lv.dD * w;
         }
         if (live) key[(long)h * nu + u] = k;
@@ -616,6 +693,7 @@ void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int
 // generates one N(D) value per MFMA (A operand), so nothing is computed twice.
 // =============================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define INTEG_THREADS 256
 #define SLICE_FLOATS (1024 * CPOL_N_SZ)      // one (e, t) node of the permuted table
@@ -674,33 +752,45 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int kq = lane >> 4, j = lane & 15;
     const float4 *B4 = (const float4 *)lds;
     const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
-    // float4 index of this lane's operand word inside quad 0 (stride 48 per quad)
-    const int boff = j < 12 ? kq * 12 + j : -1;
+    // float4 index of this lane's operand word: quad q -> bbase + q * bstride; the lanes of the
+    // four spare columns read a zero word
+    const int bbase = j < 12 ? kq * 12 + j : LDS_ZERO / 4;
+    const int bstride = j < 12 ? 48 : 0;
 
     for (int g0 = wave * 2; g0 < ngroups; g0 += 8) {
-        // two groups of 16 units per pass (two independent accumulators)
+        // two groups of 16 units per pass: two independent accumulators, and the two units'
+        // exponent arguments are formed together with packed f32 arithmetic
         int ua = g0 * 16 + j, ub = ua + 16;
-        // per unit: (hi, c) with exp(-lambda D^nu) = exp2(-hi x) * (1 + c x), x = D^nu
+        // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
         float2 la = make_float2(0.f, 0.f), lb = la;
         if (ua < cnt) la = lam[sorted[start + ua]];
         if (ub < cnt) lb = lam[sorted[start + ub]];
+        const f32x2 nhi = {-la.x, -lb.x}, nlo = {-la.y, -lb.y};
         double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
         for (int qo = 0; qo < 64; qo += 8) {
             f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
             for (int qd = qo; qd < qo + 8; qd++) {
-                float4 bq = B4[boff >= 0 ? qd * 48 + boff : LDS_ZERO / 4];
+                float4 bq = B4[bbase + qd * bstride];
                 float4 xq = X4[qd * 4];
                 const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
                 const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
+                // all eight N(D) values of the quad first (independent registers), then the
+                // eight MFMAs back to back: no MFMA waits for a transcendental result
+                float na[4], nb_[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
-                    float x = xx[s4];
-                    float ea = __builtin_amdgcn_exp2f(-(la.x * x)), eb = __builtin_amdgcn_exp2f(-(lb.x * x));
-                    float na = fmaf(ea, la.y * x, ea), nb_ = fmaf(eb, lb.y * x, eb);
-                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na, bb[s4], acca, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_, bb[s4], accb, 0, 0, 0);
+                    const f32x2 x2 = {xx[s4], xx[s4]};
+                    f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);   // one rounding of -(hi+lo)*x
+                    na[s4] = __builtin_amdgcn_exp2f(p.x);
+                    nb_[s4] = __builtin_amdgcn_exp2f(p.y);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na[s4], bb[s4], acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_[s4], bb[s4], accb, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
