@@ -573,7 +573,9 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             const PsdView &p = ct.dop[h];
             float q = vals[(long)p.q_var * plane + uu];
             float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
-            if (q > 0.f) {
+            // a negative mass density (extrapolation below the lowest level) still yields finite
+            // 2-moment parameters in the reference (clamped mean mass); the other branches give NaN
+            if (q > 0.f || (p.kind == 2 && q < 0.f)) {
                 double l, n0, vi, ni;
                 float Tp = vals[(long)p.t_var * plane + uu];
                 psd_params(p, q, qn, Tp, &l, &n0);

@@ -1,0 +1,156 @@
+"""RadarOperator with the public interface of the reference's driver class (radar_operator.py:35-425).
+
+Where the reference forks a process pool and maps one worker call per ray (:231-256), this class hands
+the whole list of rays of a scan to the GPU in one cpol_run_rays call.  With torch.distributed
+initialised (one process per GPU) the rays are sharded over the ranks and the volume is gathered on
+rank 0 (parallel.py)."""
+import numpy as np
+
+from . import cfg, model as model_mod, runtime
+from ._lib import OBS_NAMES
+from .constants import constants
+from .radar_output import SimulatedRadar
+
+BASE_VARIABLES = ['U', 'V', 'W', 'QR_v', 'QS_v', 'QG_v', 'RHO', 'T']
+BASE_VARIABLES_2MOM = ['QH_v', 'QNH_v', 'QNR_v', 'QNS_v', 'QNG_v']
+
+
+class RadarOperator(object):
+    def __init__(self, options_file='', diagnostic_mode=False, device=0):
+        if isinstance(options_file, dict):
+            cfg.set_config(options_file)
+        else:
+            cfg.init(options_file)
+        constants.update()
+        self.config = cfg
+        self.lut_sz = None
+        self.current_microphys_scheme = 1
+        self.dic_vars = {}
+        self.N = 0
+        self.diagnostic_mode = diagnostic_mode
+        self.device = device
+
+    # -- configuration / state -----------------------------------------------------------------
+    def get_config(self):
+        return cfg.CONFIG
+
+    def set_config(self, options_file):
+        if isinstance(options_file, dict):
+            cfg.set_config(options_file)
+        else:
+            cfg.init(options_file)
+        constants.update()
+
+    def set_lut(self, hydro_scheme, lut=None):
+        """lut: {class letter: Lookup_table}.  The reference reads gzip-pickled tables from
+        lookup/final_lut (lookup/read_lut.py:10-20); those files are not part of its repository, so the
+        tables have to be supplied by the caller."""
+        if lut is None:
+            raise ValueError("set_lut needs the lookup tables: {'R': Lookup_table, 'S': ..., 'G': ...[, 'H': ...]}")
+        self.lut_sz = lut
+
+    def get_pos_and_time(self):
+        c = cfg.CONFIG['radar']['coords']
+        t = self.dic_vars['T'].attributes.get('time', 0) if self.dic_vars else 0
+        return {'latitude': c[0], 'longitude': c[1], 'altitude': c[2], 'time': t}
+
+    def load_model_file(self, filename, cfilename=''):
+        """filename: path of an .npz written by cosmo_pol_amd.model.save_npz, or an already built
+        {name: ModelVariable} dictionary.  The microphysics scheme follows the variables present
+        (radar_operator.py:124-132)."""
+        dic = filename if isinstance(filename, dict) else model_mod.load_npz(filename)
+        missing = [v for v in BASE_VARIABLES if v not in dic]
+        if missing:
+            raise ValueError('Not all necessary variables could be found in file: missing %s' % missing)
+        two_mom = all(v in dic for v in BASE_VARIABLES_2MOM)
+        names = BASE_VARIABLES + (BASE_VARIABLES_2MOM if two_mom else [])
+        self.dic_vars = {k: dic[k] for k in names}
+        cfg.CONFIG['microphysics']['scheme'] = 2 if two_mom else 1
+        self.current_microphys_scheme = cfg.CONFIG['microphysics']['scheme']
+
+    # -- scans ---------------------------------------------------------------------------------
+    def _run(self, scan_type, azs, els, n_sweeps, rays_per_sweep, sweep_elev, sweep_az):
+        if not self.dic_vars:
+            print('No model file has been loaded! Aborting...')
+            return None
+        if cfg.CONFIG['radar']['type'] != 'ground':
+            print('PPI / RHI profiles only possible for ground radars')
+            return []
+        if self.lut_sz is None:
+            raise RuntimeError('lookup tables not set: call set_lut(scheme, lut) first')
+        dscheme = cfg.CONFIG['doppler']['scheme']
+        if dscheme not in (1,):
+            raise NotImplementedError('doppler.scheme %r is not available in the batched GPU path' % (dscheme,))
+        st = runtime.get_engine(self.device, doppler=dscheme, sensitivity_cut=True)
+        runtime.ensure_luts(st, self.lut_sz)
+        runtime.ensure_model(st, self.dic_vars)
+        runtime.ensure_quadrature(st)
+        ctx = st.eng.ctx
+        rank, world = _dist_info()
+        n_total = len(azs)
+        if world > 1:
+            from . import parallel
+            idx = parallel.shard_indices(n_sweeps, rays_per_sweep, rank, world)
+        else:
+            idx = np.arange(n_total)
+        out = ctx.run_rays(azs[idx], els[idx])      # raises IndexError when a gate leaves the model domain
+        fields = {n: out['obs'][i] for i, n in enumerate(OBS_NAMES)}
+        fields['RVEL'] = out['rvel']
+        extra = {'mask': out['mask'], 'lat': out['lat'], 'lon': out['lon'], 'height': out['height']}
+        if world > 1:
+            import torch
+            from . import parallel
+            g = lambda a: parallel.gather_rays(torch.as_tensor(a), idx, n_total)
+            fields = {k: g(v) for k, v in fields.items()}
+            extra = {k: g(v) for k, v in extra.items()}
+            if rank != 0:
+                return None
+            fields = {k: v.numpy() for k, v in fields.items()}
+            extra = {k: v.numpy() for k, v in extra.items()}
+        ranges = st.eng.n_gates and np.arange(cfg.CONFIG['radar']['radial_resolution'] / 2,
+                                              cfg.CONFIG['radar']['range'], cfg.CONFIG['radar']['radial_resolution'])
+        return SimulatedRadar(scan_type, els, azs, ranges, fields, extra['mask'], extra['lat'], extra['lon'],
+                              extra['height'], n_sweeps, rays_per_sweep, self.get_pos_and_time())
+
+    def get_PPI(self, elevations, azimuths=[], az_step=-1, az_start=0, az_stop=359):
+        """radar_operator.py:195-273."""
+        if np.isscalar(elevations):
+            elevations = [elevations]
+        if az_step == -1:
+            az_step = cfg.CONFIG['radar']['3dB_beamwidth']
+        if not len(azimuths):
+            if az_start > az_stop:
+                azimuths = np.hstack((np.arange(az_start, 360., az_step), np.arange(0, az_stop + az_step, az_step)))
+            else:
+                azimuths = np.arange(az_start, az_stop + az_step, az_step)
+        azimuths = np.asarray(azimuths, dtype=np.float64)
+        azs = np.tile(azimuths, len(elevations))
+        els = np.repeat(np.asarray(elevations, dtype=np.float64), len(azimuths))
+        return self._run('ppi', azs, els, len(elevations), len(azimuths), elevations, azimuths)
+
+    def get_RHI(self, azimuths, elevations=[], elev_step=-1, elev_start=0, elev_stop=90):
+        """radar_operator.py:275-348."""
+        if np.isscalar(azimuths):
+            azimuths = [azimuths]
+        if not len(elevations):
+            if elev_step == -1:
+                elev_step = cfg.CONFIG['radar']['3dB_beamwidth']
+            elevations = np.arange(elev_start, elev_stop + elev_step, elev_step)
+        elevations = np.asarray(elevations, dtype=np.float64)
+        azs = np.repeat(np.asarray(azimuths, dtype=np.float64), len(elevations))
+        els = np.tile(elevations, len(azimuths))
+        return self._run('rhi', azs, els, len(azimuths), len(elevations), elevations, azimuths)
+
+    def get_VPROF(self):
+        """radar_operator.py:153-192: one vertical ray."""
+        return self._run('vprof', np.array([0.]), np.array([90.]), 1, 1, [90.], [0.])
+
+
+def _dist_info():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1

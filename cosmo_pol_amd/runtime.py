@@ -1,0 +1,71 @@
+"""Process-wide engine cache: the reference keeps configuration, model state and lookup tables
+in module globals (utilities/cfg.py:9, radar_operator.py:71-84); the GPU context plays that role
+here.  One engine per (device); model / tables are re-uploaded only when the caller hands in a
+different object."""
+import copy
+
+from . import cfg, engine
+
+_engines = {}
+
+
+class _State(object):
+    def __init__(self):
+        self.eng = None
+        self.conf_snapshot = None
+        self.model_key = None
+        self.lut_key = None
+        self.quad_key = None
+
+
+def get_engine(device=0, doppler=None, sensitivity_cut=False):
+    st = _engines.setdefault(device, _State())
+    conf = cfg.CONFIG if cfg.CONFIG else cfg.DEFAULTS
+    snap = (copy.deepcopy(conf), doppler, sensitivity_cut)
+    if st.eng is None:
+        st.eng = engine.Engine(conf, device=device)
+        st.conf_snapshot = None
+    if st.conf_snapshot != snap:
+        st.eng.configure(conf, doppler=doppler, sensitivity_cut=sensitivity_cut)
+        st.conf_snapshot = snap
+        st.quad_key = None
+        if st.lut_key is not None and st.lut_key[1] != conf['microphysics']['scheme']:
+            st.lut_key = None
+    return st
+
+
+def ensure_luts(st, lut_sz):
+    key = (id(lut_sz), st.eng.conf['microphysics']['scheme'])
+    if st.lut_key != key:
+        st.eng.upload_luts(lut_sz)
+        st.lut_key = key
+
+
+def ensure_model(st, dic_variables):
+    key = id(dic_variables)
+    if st.model_key != key:
+        first = next(iter(dic_variables.values()))
+        fields = {k: v.data for k, v in dic_variables.items()}
+        st.eng.upload_model(fields, first.attributes['z-levels'], first.attributes['proj_info'],
+                            first.attributes['resolution'])
+        st.model_key = key
+
+
+def ensure_quadrature(st):
+    c = st.eng.conf
+    key = (c['integration']['scheme'], c['integration']['nh_GH'], c['integration']['nv_GH'],
+           c['integration']['weight_threshold'], c['radar']['3dB_beamwidth'])
+    if st.quad_key != key:
+        if c['integration']['scheme'] != 1:
+            raise NotImplementedError("only integration scheme 1 (Gauss-Hermite) generates its own sub-beams; "
+                                      "pass other point sets through Engine.ctx.set_quadrature")
+        st.quad = st.eng.set_gauss_hermite()
+        st.quad_key = key
+    return st.quad
+
+
+def reset():
+    for st in _engines.values():
+        if st.eng is not None:
+            st.eng.ctx.close()
+    _engines.clear()

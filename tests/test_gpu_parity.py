@@ -260,3 +260,84 @@ def test_run_rays_out_of_domain():
         eng.ctx.run_rays(np.array([90.]), np.array([1.0]))
     out = eng.ctx.run_rays(np.array([90.]), np.array([1.0]), raise_on_domain=False)
     assert out['ray_status'][0] == _lib.ERR_DOMAIN
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference-named Python API on top of the C ABI
+# ---------------------------------------------------------------------------------------------
+def _api_setup(scheme, nh, nv, dscheme=1, sens=None):
+    from cosmo_pol_amd import cfg as pcfg, model as pmodel, runtime
+    from cosmo_pol_amd.constants import constants
+    conf = pipeline_conf(scheme, nh, nv, dscheme=dscheme)
+    if sens is not None:
+        conf['radar']['sensitivity'] = sens
+    runtime.reset()
+    pcfg.set_config(conf)
+    constants.update()
+    m = pipeline_model(scheme)
+    dic = pmodel.variables_from_arrays(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    tabs = util.synthetic_lut_arrays(scheme, 5.6)
+    luts = {h: Lookup_table.from_arrays(*t) for h, t in tabs.items()}
+    return conf, m, dic, luts
+
+
+def test_api_functions_vs_oracle():
+    """interpolation.get_profiles_GH -> doppler_sz.get_doppler_velocity -> scattering_sz.get_radar_observables,
+    called like radar_operator.py:241-243 does."""
+    from cosmo_pol_amd import interpolation, scattering_sz, doppler_sz
+    conf, m, dic, luts = _api_setup(2, 3, 3)
+    az, el = 123.0, 4.0
+    beams = interpolation.get_profiles_GH(dic, az, el)
+    with np.errstate(all='ignore'):
+        want_b = O.get_profiles_GH(oracle_model_vars(m), az, el, conf)
+    assert len(beams) == len(want_b) == 9
+    for b, w in zip(beams, want_b):
+        np.testing.assert_array_equal(b.mask, w.mask)
+        np.testing.assert_array_equal(b.dist_profile, w.dist_profile)
+        np.testing.assert_array_equal(b.heights_profile, w.heights_profile)
+        assert b.GH_weight == w.GH_weight and list(b.GH_pt) == list(w.GH_pt)
+        for k in w.values:
+            np.testing.assert_array_equal(b.values[k].view(np.int32), w.values[k].view(np.int32))
+    dop = doppler_sz.get_doppler_velocity(beams, luts)
+    pol = scattering_sz.get_radar_observables(beams, luts)
+    olut = util.oracle_luts(2, 5.6)
+    with np.errstate(all='ignore'):
+        want_v = O.get_doppler_velocity(want_b, olut, conf)
+        want = O.get_radar_observables(want_b, olut, conf)
+    check_obs(np.stack([pol.values[n] for n in OBS]), want.values, 'api')
+    util.assert_close(dop.values['RVEL'], want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+    np.testing.assert_array_equal(pol.mask, want.mask)
+    # the in-place folding of the reference is reproduced
+    np.testing.assert_array_equal(beams[0].elev_profile, want_b[0].elev_profile)
+
+
+def test_radar_operator_ppi_with_sensitivity_cut():
+    from cosmo_pol_amd import RadarOperator
+    conf, m, dic, luts = _api_setup(1, 1, 1, sens=[10, 10000])
+    op = RadarOperator(conf)
+    op.load_model_file(dic)
+    assert op.get_config()['microphysics']['scheme'] == 1
+    op.set_lut(1, luts)
+    radar = op.get_PPI([2.0, 6.0], az_step=90, az_start=0, az_stop=270)
+    assert radar.nrays == 8 and radar.fields['ZH']['data'].shape == (8, 40)
+    olut = util.oracle_luts(1, 5.6)
+    cut = 0
+    for s, el in enumerate([2.0, 6.0]):
+        zh = radar.get_field(s, 'ZH')
+        for i, az in enumerate([0., 90., 180., 270.]):
+            with np.errstate(all='ignore'):
+                beams = O.get_profiles_GH(oracle_model_vars(m), az, el, conf)
+                v = O.get_doppler_velocity(beams, olut, conf)
+                b = O.get_radar_observables(beams, olut, conf)
+                b.values.update(v.values)
+                pre = np.isfinite(b.values['ZH']).sum()
+                O.cut_at_sensitivity([b], conf)
+                cut += pre - np.isfinite(b.values['ZH']).sum()
+                want_db = 10 * np.log10(b.values['ZH'])
+            got = zh[i].filled(np.nan)
+            np.testing.assert_array_equal(np.isnan(got), np.isnan(want_db))
+            ok = ~np.isnan(want_db)
+            assert np.abs(got[ok] - want_db[ok]).max() < 0.01
+            rv = radar.get_field(s, 'RVEL')[i].filled(np.nan)
+            util.assert_close(rv, b.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+    assert cut > 0          # the cut was exercised
