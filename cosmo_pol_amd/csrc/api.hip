@@ -129,10 +129,8 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->dcol) hipFree(ctx->dcol);
     if (ctx->quad_dev) hipFree(ctx->quad_dev);
     for (auto &l : ctx->lut) {
-        if (l.table) hipFree(l.table);
-        if (l.xq) hipFree(l.xq);
-        if (l.xmu) hipFree(l.xmu);
-        if (l.d_axis) hipFree(l.d_axis);
+        float *owned[] = {l.raw, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
+        for (float *q : owned) if (q) hipFree(q);
     }
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
     if (ctx->valid_host) hipHostFree(ctx->valid_host);
@@ -157,8 +155,8 @@ extern "C" int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg)
     if (!ctx || !cfg) return CPOL_ERR_ARG;
     if (cfg->n_gates <= 0 || cfg->range_res <= 0) return fail(ctx, CPOL_ERR_ARG, "n_gates and range_res must be positive");
     if (cfg->microphysics_scheme != 1 && cfg->microphysics_scheme != 2) return fail(ctx, CPOL_ERR_ARG, "microphysics_scheme must be 1 or 2");
-    if (cfg->doppler_scheme < 0 || cfg->doppler_scheme > 1)
-        return fail(ctx, CPOL_ERR_ARG, "doppler_scheme: only 0 (off) and 1 are implemented in the batched path");
+    if (cfg->doppler_scheme < 0 || cfg->doppler_scheme > 2)
+        return fail(ctx, CPOL_ERR_ARG, "doppler_scheme: 0 (off), 1 and 2 are implemented in the batched path");
     ctx->cfg = *cfg;
     if (ctx->cfg.earth_radius == 0) {
         // atm_refraction.py:18-21 evaluated at coords[1] taken as radians (:114-117)
@@ -224,42 +222,15 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
         return fail(ctx, CPOL_ERR_ARG, "bad psd descriptor");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     LutDev &L = ctx->lut[cls];
-    if (L.table) hipFree(L.table);
-    if (L.xq) hipFree(L.xq);
-    if (L.xmu) hipFree(L.xmu);
-    if (L.d_axis) hipFree(L.d_axis);
+    float **owned[] = {&L.raw, &L.table, &L.xq, &L.table_dop, &L.xq_dop, &L.d_axis};
+    for (float **q : owned) if (*q) { HIPCHK(ctx, hipFree(*q)); }
     L = LutDev();
     size_t nt = (size_t)lut->n_e * lut->n_t * lut->n_d * CPOL_N_SZ;
-    HIPCHK(ctx, hipMalloc((void **)&L.table, nt * sizeof(float)));
-    HIPCHK(ctx, hipMalloc((void **)&L.xq, 1024 * sizeof(float)));
-    HIPCHK(ctx, hipMalloc((void **)&L.xmu, 1024 * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&L.raw, nt * sizeof(float)));
     HIPCHK(ctx, hipMalloc((void **)&L.d_axis, 1024 * sizeof(float)));
-    std::vector<float> dax(1024), xq(1024), xmu(1024);
+    HIPCHK(ctx, hipMemcpy(L.raw, lut->table, nt * sizeof(float), hipMemcpyDefault));
+    std::vector<float> dax(1024);
     HIPCHK(ctx, hipMemcpy(dax.data(), lut->d_axis, 1024 * sizeof(float), hipMemcpyDefault));
-    for (int d = 0; d < 1024; d++) {
-        // D^nu in the order the integrate kernel reads it: [d/16][d%4][(d/4)%4]
-        int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
-        xq[(qd * 4 + kk) * 4 + s4] = (float)pow((double)dax[d], psd->nu);
-        xmu[d] = (float)pow((double)dax[d], psd->mu);
-    }
-    {
-        // permuted, D^mu-weighted image of every (e, t) slice: see k_integrate
-        std::vector<float> host(nt), img(nt);
-        HIPCHK(ctx, hipMemcpy(host.data(), lut->table, nt * sizeof(float), hipMemcpyDefault));
-        const size_t nslice = (size_t)lut->n_e * lut->n_t;
-        for (size_t sl = 0; sl < nslice; sl++) {
-            const float *src = host.data() + sl * 1024 * CPOL_N_SZ;
-            float *dst = img.data() + sl * 1024 * CPOL_N_SZ;
-            for (int d = 0; d < 1024; d++) {
-                int qd = d >> 4, s4 = (d >> 2) & 3, kk = d & 3;
-                for (int j = 0; j < CPOL_N_SZ; j++)
-                    dst[((qd * 48 + kk * 12 + j) << 2) + s4] = src[d * CPOL_N_SZ + j] * xmu[d];
-            }
-        }
-        HIPCHK(ctx, hipMemcpy(L.table, img.data(), nt * sizeof(float), hipMemcpyHostToDevice));
-    }
-    HIPCHK(ctx, hipMemcpy(L.xq, xq.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(L.xmu, xmu.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(L.d_axis, dax.data(), 1024 * sizeof(float), hipMemcpyHostToDevice));
     L.n_e = lut->n_e; L.n_t = lut->n_t; L.n_d = lut->n_d;
     L.e_min = lut->e_min; L.e_step = lut->e_step; L.t_min = lut->t_min; L.t_step = lut->t_step;
@@ -288,22 +259,62 @@ extern "C" int cpol_set_quadrature(cpol_ctx *ctx, int n_sub, const double *az_of
 }
 
 // ------------------------------------------------------------------------------------
+static bool same_psd(const cpol_psd &a, const cpol_psd &b)
+{
+    return a.psd_kind == b.psd_kind && a.a == b.a && a.b == b.b && a.alpha == b.alpha && a.beta == b.beta &&
+           a.mu == b.mu && a.nu == b.nu && a.lambda_factor == b.lambda_factor && a.n0_fixed == b.n0_fixed &&
+           a.x_min == b.x_min && a.x_max == b.x_max && a.q_var == b.q_var && a.qn_var == b.qn_var &&
+           (a.psd_kind != 1 || a.t_var == b.t_var || (a.t_var < 0 && b.t_var < 0));
+}
+
+// Class table of the configured schemes; (re)builds the lookup-table images when the column
+// layout they were built for differs from what the configuration needs.
 static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
 {
     memset(&ct, 0, sizeof(ct));
     ct.n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
+    const bool dop2 = ctx->cfg.doppler_scheme == 2;
+    ct.ncol = dop2 ? 14 : 12;
+    bool shared = dop2;
     for (int h = 0; h < ct.n_cls; h++) {
-        const LutDev &L = ctx->lut[h];
-        if (!L.present) return fail(ctx, CPOL_ERR_STATE, "a lookup table of the microphysics scheme is missing");
+        if (!ctx->lut[h].present) return fail(ctx, CPOL_ERR_STATE, "a lookup table of the microphysics scheme is missing");
+        shared = shared && same_psd(ctx->lut[h].psd, ctx->lut[h].psd_dop);
+    }
+    ct.dop_shared = shared ? 1 : 0;
+    ct.n_kinds = (dop2 && !shared) ? 2 : 1;
+    for (int h = 0; h < ct.n_cls; h++) {
+        LutDev &L = ctx->lut[h];
+        const long nslice = (long)L.n_e * L.n_t;
+        const size_t img_bytes = (size_t)nslice * 1024 * ct.ncol * sizeof(float);
+        const int want_dop_img = ct.n_kinds == 2 ? 1 : 0;
+        const int tag = ct.ncol * 4 + (shared ? 2 : 0) + want_dop_img;
+        if (L.image_ncol != tag) {
+            if (L.table) { HIPCHK(ctx, hipFree(L.table)); L.table = nullptr; }
+            if (L.table_dop) { HIPCHK(ctx, hipFree(L.table_dop)); L.table_dop = nullptr; }
+            if (!L.xq) HIPCHK(ctx, hipMalloc((void **)&L.xq, 1024 * sizeof(float)));
+            if (!L.xq_dop) HIPCHK(ctx, hipMalloc((void **)&L.xq_dop, 1024 * sizeof(float)));
+            HIPCHK(ctx, hipMalloc((void **)&L.table, img_bytes));
+            launch_build_image(ctx->stream, L.raw, L.d_axis, L.table, L.xq, nslice, ct.ncol, L.psd.mu, L.psd.nu,
+                               shared ? 1 : 0, 0, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta);
+            if (want_dop_img) {
+                HIPCHK(ctx, hipMalloc((void **)&L.table_dop, img_bytes));
+                launch_build_image(ctx->stream, L.raw, L.d_axis, L.table_dop, L.xq_dop, nslice, ct.ncol, L.psd_dop.mu,
+                                   L.psd_dop.nu, 1, 1, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            L.image_ncol = tag;
+        }
         LutView &v = ct.lut[h];
-        v.table = L.table; v.xq = L.xq; v.xmu = L.xmu; v.n_e = L.n_e; v.n_t = L.n_t; v.n_d = L.n_d;
+        v.table = L.table; v.xq = L.xq; v.n_e = L.n_e; v.n_t = L.n_t; v.n_d = L.n_d;
         v.e_min = L.e_min; v.e_step = L.e_step; v.t_min = L.t_min; v.t_step = L.t_step; v.dD = L.dD;
+        ct.lut_dop[h] = v;
+        ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
         fill_psd(ct.psd[h], L.psd);
         fill_psd(ct.dop[h], L.psd_dop);
         if (L.n_e > ct.ne_max) ct.ne_max = L.n_e;
         if (L.n_t > ct.nt_max) ct.nt_max = L.n_t;
     }
-    if ((long)ct.n_cls * ct.ne_max * ct.nt_max > 8192) return fail(ctx, CPOL_ERR_ARG, "more than 8192 lookup-table nodes");
+    if ((long)ct.n_kinds * ct.n_cls * ct.ne_max * ct.nt_max > 16384) return fail(ctx, CPOL_ERR_ARG, "more than 16384 lookup-table nodes");
     return CPOL_OK;
 }
 
@@ -343,8 +354,9 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
                        float *obs, long obs_plane, long ray0, double *mask_out, double *rvel_out)
 {
     const long nu = (long)nr * B * G;
-    const long nslots = nu * ct.n_cls;
-    const int nb = ct.n_cls * ct.ne_max * ct.nt_max;
+    const int n_planes = ct.n_kinds * ct.n_cls;
+    const long nslots = nu * n_planes;
+    const int nb = n_planes * ct.ne_max * ct.nt_max;
     TRY(ensure(ctx, ctx->b_key, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
@@ -353,16 +365,17 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->b_psd, (size_t)nslots * CPOL_N_COL * sizeof(float)));
     TRY(ensure(ctx, ctx->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
+    if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->b_n0d, nslots * sizeof(double)));
     int *hist = (int *)ctx->b_hist.p, *cursor = hist + CPOL_SORT_SHARDS * (nb + 1), *offs = cursor + CPOL_SORT_SHARDS * (nb + 1),
         *chunk_off = offs + (nb + 1);
     {
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
     launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme,
-                (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p, hist,
-                (double *)ctx->b_vr.p);
+                (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
+                (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, hist, offs, cursor, chunk_off);
-    launch_scatter(ctx->stream, nu, ct.n_cls, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, cursor,
+    launch_scatter(ctx->stream, nu, n_planes, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, cursor,
                    (int *)ctx->b_sorted.p);
     }
     if (ctx->timing) {
@@ -385,10 +398,21 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
+    Dop2In d2;
+    memset(&d2, 0, sizeof(d2));
+    if (ctx->cfg.doppler_scheme == 2) {
+        d2.vals = vals; d2.plane = plane; d2.elev = elev; d2.phi_sc = phi;
+        d2.lam = (const float2 *)ctx->b_lam.p; d2.n0d = (const double *)ctx->b_n0d.p;
+        d2.n_cls = ct.n_cls; d2.ne_max = ct.ne_max; d2.nt_max = ct.nt_max; d2.ncol = ct.ncol; d2.shared = ct.dop_shared;
+        for (int h = 0; h < ct.n_cls; h++) {
+            const LutView &v = ct.dop_shared ? ct.lut[h] : ct.lut_dop[h];
+            d2.img[h] = v.table; d2.xq[h] = v.xq; d2.n_t[h] = v.n_t;
+        }
+    }
     StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
     launch_observables(ctx->stream, op, nr, nu, (const int *)ctx->b_key.p, (const double *)ctx->b_coef.p,
                        (const float *)ctx->b_psd.p, mask, wsub, (const double *)ctx->b_vr.p, obs, obs_plane, ray0,
-                       mask_out, rvel_out);
+                       mask_out, rvel_out, d2);
     HIPCHK(ctx, hipGetLastError());
     return CPOL_OK;
 }

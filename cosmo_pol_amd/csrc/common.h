@@ -16,10 +16,14 @@ struct LutDev {
     int    n_e = 0, n_t = 0, n_d = 0;
     float  e_min = 0, e_step = 1, t_min = 0, t_step = 1;
     float  dD = 0;                 // D[1]-D[0] in float32 (scattering_sz.py:50)
-    float *table = nullptr;        // [n_e][n_t] slices of 1024 x 12, permuted and pre-multiplied by D^mu (see k_integrate)
+    float *raw = nullptr;          // [n_e][n_t][1024][12] as uploaded
+    float *table = nullptr;        // [n_e][n_t] slices of 1024 x ncol, permuted and pre-multiplied by D^mu (see k_integrate)
     float *xq = nullptr;           // D^nu, permuted for the integrate kernel's ds_read_b128
-    float *xmu = nullptr;          // D^mu
+    float *table_dop = nullptr;    // same for the separate Doppler units (2-moment input + doppler scheme 2)
+    float *xq_dop = nullptr;
     float *d_axis = nullptr;       // [n_d]
+    int    image_ncol = 0;         // what `table` was last built for
+    bool   image_dop = false;
     cpol_psd psd, psd_dop;
 };
 
@@ -27,7 +31,6 @@ struct LutDev {
 struct LutView {
     const float *table;
     const float *xq;
-    const float *xmu;
     int   n_e, n_t, n_d;
     float e_min, e_step, t_min, t_step;
     float dD;
@@ -42,8 +45,12 @@ struct PsdView {
 
 struct ClassTable {
     int     n_cls;
-    int     ne_max, nt_max;        // bucket id = (cls*ne_max + ie)*nt_max + it
+    int     ne_max, nt_max;        // bucket id = ((kind*n_cls + cls)*ne_max + ie)*nt_max + it
+    int     n_kinds;               // 1, or 2 when Doppler scheme 2 needs units of its own (kind 1)
+    int     ncol;                  // 12, or 14 with the two Doppler scheme-2 moments
+    int     dop_shared;            // Doppler moments ride on the polarimetric units (identical PSD)
     LutView lut[CPOL_MAX_CLASSES];
+    LutView lut_dop[CPOL_MAX_CLASSES];
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
 };
@@ -94,7 +101,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     std::vector<Buf *> bufs;
     Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-        b_sorted, b_rank, b_psd, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+        b_sorted, b_rank, b_psd, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
         o_obs, o_rvel, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)8 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
@@ -128,17 +135,31 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
                    float *vals, long plane, signed char *mask, float *raw_out);
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                  const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
-                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, int *hist,
-                 double *vr);
+                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, double *n0d,
+                 int *hist, double *vr);
+void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
+                        int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
+                        double beta_d);
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off);
-void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *cursor, int *sorted);
+void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
+struct Dop2In {                    // inputs of the Doppler scheme-2 reduction inside k_observables
+    const float  *vals; long plane;
+    const float  *elev;
+    const double *phi_sc;
+    const float2 *lam;
+    const double *n0d;
+    int n_cls, ne_max, nt_max, ncol, shared;
+    const float *img[CPOL_MAX_CLASSES];   // table image holding the Doppler columns
+    const float *xq[CPOL_MAX_CLASSES];
+    int n_t[CPOL_MAX_CLASSES];
+};
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
-                        long ray0, double *mask_out, double *rvel_out);
+                        long ray0, double *mask_out, double *rvel_out, const Dop2In &d2);
 void launch_gather_central(hipStream_t s, int n_rays, int n_sub, int n_gates, const float *S, const float *H,
                            const double *lat, const double *lon, float *dist, float *height, double *olat,
                            double *olon, long ray0);

@@ -463,6 +463,49 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
 }
 
 // =============================================================================
+// Lookup-table image for k_integrate, built on the device whenever tables or schemes change:
+//   img[((q*4*ncol + k*ncol + j) * 4 + s] = B'[d][j],  d = 16 q + 4 s + k
+//   B'[d][j <  12] = sz[d][j] * D^mu                       (scattering_sz.py:95-103, PSD weight folded in)
+//   B'[d][12]      = rcs[d] * D^mu_d,  B'[d][13] = rcs[d] * v(D) * D^mu_d     (doppler_sz.py:192,218-220)
+// with rcs = 2 pi (sz0 - sz1 - sz2 + sz3) and v = alpha D^beta in float32 as in the reference.
+// xq[(q*4 + k)*4 + s] = D^nu in the same permuted order.
+// =============================================================================
+__global__ void k_build_image(const float *__restrict__ raw, const float *__restrict__ d_axis, float *__restrict__ img,
+                              float *__restrict__ xq, long nslice, int ncol, double mu, double nu, int with_dop,
+                              int zero_pol, double mu_d, double alpha_d, double beta_d)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = nslice * 1024 * ncol;
+    if (t >= total) return;
+    int j = (int)(t % ncol);
+    int d = (int)((t / ncol) % 1024);
+    long sl = t / ((long)ncol * 1024);
+    float D = d_axis[d];
+    const float *src = raw + (sl * 1024 + d) * CPOL_N_SZ;
+    float val;
+    if (j < CPOL_N_SZ) val = zero_pol ? 0.f : src[j] * (float)pow((double)D, mu);
+    else if (!with_dop) val = 0.f;
+    else {
+        float rcs = (float)(2 * M_PI) * (((src[0] - src[1]) - src[2]) + src[3]);
+        float xm = (float)pow((double)D, mu_d);
+        val = rcs * xm;
+        if (j == 13) val = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * xm;
+    }
+    int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
+    img[sl * 1024 * ncol + (((long)(q * 4 + k) * ncol + j) << 2) + s4] = val;
+    if (sl == 0 && j == 0) xq[((q * 4 + k) << 2) + s4] = (float)pow((double)D, nu);
+}
+
+void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
+                        int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
+                        double beta_d)
+{
+    long total = nslice * 1024 * ncol;
+    hipLaunchKernelGGL(k_build_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, d_axis, img, xq, nslice,
+                       ncol, mu, nu, with_dop, zero_pol, mu_d, alpha_d, beta_d);
+}
+
+// =============================================================================
 // PSD set-up per (gate, sub-beam, class): valid test, nearest lookup-table node,
 // PSD parameters (hydrometeors.py set_psd), bucket histogram; Doppler scheme 1
 // radial velocity per sub-beam.
@@ -527,7 +570,8 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
                        const float *__restrict__ elev, const signed char *__restrict__ mask,
                        const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
                        int *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
-                       double *__restrict__ coef, int *__restrict__ hist, double *__restrict__ vr)
+                       double *__restrict__ coef, double *__restrict__ n0d, int *__restrict__ hist,
+                       double *__restrict__ vr)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int lane = threadIdx.x & 63;
@@ -556,6 +600,7 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             float hi = (float)l2;
             lam[(long)h * nu + u] = make_float2(hi, (float)(l2 - (double)hi));
             coef[(long)h * nu + u] = n0 * (double)lv.dD * w;
+            if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = n0;
         }
         if (live) key[(long)h * nu + u] = k;
         // position of the unit inside its (bucket, shard) counter: one atomic per run of equal keys
@@ -565,6 +610,32 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
         if (k >= 0 && hl == lane) base = atomicAdd(&hist[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))], len);
         base = __shfl(base, hl);
         if (k >= 0) rank[(long)h * nu + u] = base + (lane - hl);
+        if (ct.n_kinds == 2) {
+            // Doppler scheme 2 with a PSD of its own (doppler_sz.py:57: 1-moment classes fed the
+            // 2-moment variables): same table node, separate unit (kind 1)
+            const PsdView &pd = ct.dop[h];
+            const long dslot = (long)(ct.n_cls + h) * nu + u;
+            int kd = -1;
+            if (valid) {
+                kd = k + ct.n_cls * ct.ne_max * ct.nt_max;
+                float qd = vals[(long)pd.q_var * plane + uu];
+                float qnd = pd.qn_var >= 0 ? vals[(long)pd.qn_var * plane + uu] : 0.f;
+                float Td = vals[(long)pd.t_var * plane + uu];
+                double l, n0;
+                psd_params(pd, qd, qnd, Td, &l, &n0);
+                if (qd == 0.f) l = __builtin_nan("");
+                double l2 = l * 1.4426950408889634;
+                float hi = (float)l2;
+                lam[dslot] = make_float2(hi, (float)(l2 - (double)hi));
+                n0d[dslot] = n0;
+            }
+            if (live) key[dslot] = kd;
+            wave_run(kd, lane, &hl, &len);
+            base = 0;
+            if (kd >= 0 && hl == lane) base = atomicAdd(&hist[kd * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))], len);
+            base = __shfl(base, hl);
+            if (kd >= 0) rank[dslot] = base + (lane - hl);
+        }
     }
     if (doppler == 1 && live) {
         // doppler_sz.py:130-153 (closed-form PSD-weighted fall speed) and :75-87 (projection)
@@ -616,11 +687,11 @@ void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc)
 
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                  const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
-                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, int *hist,
-                 double *vr)
+                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, double *n0d,
+                 int *hist, double *vr)
 {
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, ct, nu, n_gates, vals, plane,
-                       elev, mask, weight_per_sub, n_sub, phi_sc, doppler, key, rank, lam, coef, hist, vr);
+                       elev, mask, weight_per_sub, n_sub, phi_sc, doppler, key, rank, lam, coef, n0d, hist, vr);
 }
 
 // Exclusive scan of the sharded bucket histogram (nb <= 8192 buckets x CPOL_SORT_SHARDS
@@ -682,9 +753,9 @@ __global__ void k_scatter(long nu, const int *__restrict__ key, const int *__res
     if (k >= 0) sorted[cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
 }
 
-void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *cursor, int *sorted)
+void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_cls), dim3(256), 0, s, nu, key, rank, cursor, sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, key, rank, cursor, sorted);
 }
 
 // =============================================================================
@@ -698,18 +769,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define INTEG_THREADS 256
-#define SLICE_FLOATS (1024 * CPOL_N_SZ)      // one (e, t) node of the permuted table
-#define LDS_ZERO SLICE_FLOATS                // 4 zero floats read by the lanes of columns 12..15
-#define LDS_X (SLICE_FLOATS + 4)
 
-// Table image (global and LDS alike), built once at upload (api.hip, permute_table):
-//   img[((q*48 + k*12 + j) * 4 + s] = sz[d][j] * D_d^mu   with d = 16 q + 4 s + k
+// Table image (global and LDS alike, built by k_build_image):
+//   img[((q*4*NC + k*NC + j) * 4 + s] = B'[d][j]   with d = 16 q + 4 s + k
 // i.e. for the quad q of four consecutive MFMA steps s = 0..3, the lane (k = lane >> 4,
-// j = lane & 15 < 12) finds its four B operands in one 16-byte word.
-__global__ __launch_bounds__(INTEG_THREADS, 3)
+// j = lane & 15 < NC) finds its four B operands in one 16-byte word.  NC = 12 (three
+// workgroups per CU) or 14 with the two Doppler scheme-2 moments (two per CU).
+template <int NC>
+__global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                  const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
 {
+    constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
+    constexpr int LDS_ZERO = SLICE_FLOATS;       // 4 zero floats read by the lanes of the spare columns
+    constexpr int LDS_X = SLICE_FLOATS + 4;
     __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 4 + 1024];
 
     // XCD-aware chunk order: workgroups that share an XCD (blockIdx % 8) take consecutive
@@ -734,8 +807,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 
     const int it = bkt % ct.nt_max;
     const int ie = (bkt / ct.nt_max) % ct.ne_max;
-    const int h = bkt / (ct.nt_max * ct.ne_max);
-    const LutView lv = ct.lut[h];
+    const int hk = bkt / (ct.nt_max * ct.ne_max);          // kind * n_cls + class
+    const LutView lv = hk < ct.n_cls ? ct.lut[hk] : ct.lut_dop[hk - ct.n_cls];
     const int tid = threadIdx.x;
 
     // ---- stage the slice: straight 16-byte copy of the pre-permuted image ----
@@ -744,6 +817,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         float4 *dst = (float4 *)lds;
 #pragma unroll
         for (int i = 0; i < SLICE_FLOATS / 4 / INTEG_THREADS; i++) dst[tid + i * INTEG_THREADS] = src[tid + i * INTEG_THREADS];
+        static_assert(SLICE_FLOATS % (4 * INTEG_THREADS) == 0, "slice must be a whole number of 16-byte rounds");
         ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
         if (tid == 0) *(float4 *)(lds + LDS_ZERO) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -756,8 +830,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
     // float4 index of this lane's operand word: quad q -> bbase + q * bstride; the lanes of the
     // four spare columns read a zero word
-    const int bbase = j < 12 ? kq * 12 + j : LDS_ZERO / 4;
-    const int bstride = j < 12 ? 48 : 0;
+    const int bbase = j < NC ? kq * NC + j : LDS_ZERO / 4;
+    const int bstride = j < NC ? 4 * NC : 0;
 
     for (int g0 = wave * 2; g0 < ngroups; g0 += 8) {
         // two groups of 16 units per pass: two independent accumulators, and the two units'
@@ -798,7 +872,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
         }
         // C/D layout: column = lane & 15 (component), row = (lane >> 4) * 4 + r (unit in group)
-        if (j < CPOL_N_SZ) {
+        if (j < NC) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int row = kq * 4 + r;
@@ -814,8 +888,12 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
                       const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out)
 {
     if (max_chunks <= 0) return;
-    hipLaunchKernelGGL(k_integrate, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                       sorted, lam, psd_out);
+    if (ct.ncol == 12)
+        hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
+                           sorted, lam, psd_out);
+    else
+        hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
+                           sorted, lam, psd_out);
 }
 
 // =============================================================================
@@ -835,11 +913,49 @@ __device__ inline double wave_scan_incl(double x, int lane)
     return x;
 }
 
+// Doppler scheme 2 (doppler_sz.py:155-231) for one (ray, sub-beam, gate): RCS- and PSD-weighted mean fall
+// speed over the classes from the two extra columns of the PSD integration, unit-spacing trapezoid rule
+// (sum minus half of the end terms, :219-220), air-density correction and projection on the beam (:23,231).
+__device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict__ key, const float *__restrict__ psd_out,
+                                         long nu, long u, long rb, int G)
+{
+    double vh = 0., nn = 0.;
+    bool any = false;
+    for (int h = 0; h < d2.n_cls; h++) {
+        const long slot = (long)(d2.shared ? h : d2.n_cls + h) * nu + u;
+        int k = key[slot];
+        if (k < 0) continue;
+        any = true;
+        const int it = k % d2.nt_max, ie = (k / d2.nt_max) % d2.ne_max;
+        const int NC = d2.ncol;
+        const float *img = d2.img[h] + (long)(ie * d2.n_t[h] + it) * 1024 * NC;
+        const float2 l = d2.lam[slot];
+        const double l2 = (double)l.x + (double)l.y;
+        const double e0 = exp2(-l2 * (double)d2.xq[h][0]), e1 = exp2(-l2 * (double)d2.xq[h][1023]);
+        // B'[d][j] at d = 0 and d = 1023 (q = 63, s = 3, k = 3)
+        const long i0 = 0, i1 = (((long)(63 * 4 + 3) * NC) << 2) + 3;
+        double s12 = (double)psd_out[slot * CPOL_N_COL + 12] - 0.5 * (e0 * (double)img[i0 + 12 * 4] + e1 * (double)img[i1 + 12 * 4]);
+        double s13 = (double)psd_out[slot * CPOL_N_COL + 13] - 0.5 * (e0 * (double)img[i0 + 13 * 4] + e1 * (double)img[i1 + 13 * 4]);
+        double n0 = d2.n0d[slot];
+        double a = n0 * s13, b = n0 * s12;
+        vh += (a != a ? 0. : a);
+        nn += (b != b ? 0. : b);
+    }
+    double vhyd = any ? vh / nn : __builtin_nan("");
+    float rho = d2.vals[(long)CPOL_V_RHO * d2.plane + u];
+    float rho0 = d2.vals[(long)CPOL_V_RHO * d2.plane + rb * G];
+    vhyd *= (double)sqrtf(rho / rho0);
+    float th = d2.elev[u] * (float)(M_PI / 180.0);
+    double U = d2.vals[(long)CPOL_V_U * d2.plane + u], V = d2.vals[(long)CPOL_V_V * d2.plane + u];
+    double W = d2.vals[(long)CPOL_V_W * d2.plane + u];
+    return (U * d2.phi_sc[2 * rb] + V * d2.phi_sc[2 * rb + 1]) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
+}
+
 __global__ __launch_bounds__(64)
 void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
-                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out)
+                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
     const int G = op.n_gates, B = op.n_sub;
@@ -879,7 +995,8 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
                 long u = ((long)r * B + b) * G + g;
                 msum += (double)mask[u];
                 if (op.doppler) {
-                    double pw = vr[u], w = wsub[b];
+                    double pw = op.doppler == 2 ? doppler2_radial(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
+                    double w = wsub[b];
                     sw += (pw != pw) ? 0. : w;
                     double t = pw * w;
                     rv = (rv != rv ? 0. : rv) + (t != t ? 0. : t);
@@ -956,10 +1073,10 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
-                        long ray0, double *mask_out, double *rvel_out)
+                        long ray0, double *mask_out, double *rvel_out, const Dop2In &d2)
 {
     hipLaunchKernelGGL(k_observables, dim3(n_rays), dim3(64), 0, s, op, n_rays, nu, key, coef, psd_out, mask,
-                       weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out);
+                       weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
 }
 
 // geometry of the central sub-beam (scattering_sz.py:154-157)

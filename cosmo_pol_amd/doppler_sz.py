@@ -1,6 +1,6 @@
-"""get_doppler_velocity with the reference signature (doppler/doppler_sz.py:26).  Scheme 1 (PSD-weighted
-fall speed, closed form) runs in the HIP kernels; schemes 2 and 3 are not part of the batched path yet
-and raise."""
+"""get_doppler_velocity with the reference signature (doppler/doppler_sz.py:26).  Scheme 1 (PSD-weighted fall
+speed, closed form) and scheme 2 (RCS- and PSD-weighted, two extra columns of the PSD integration) run in the
+HIP kernels; scheme 3 (full spectrum) is not part of the batched path yet and raises."""
 import numpy as np
 
 from . import cfg, runtime
@@ -10,10 +10,10 @@ from .scattering_sz import _pack
 
 def get_doppler_velocity(list_beams, lut_sz=0, device=0):
     scheme = cfg.CONFIG['doppler']['scheme']
-    if scheme != 1:
-        raise NotImplementedError("doppler.scheme %r: only scheme 1 runs on the GPU path; the reference's "
+    if scheme not in (1, 2):
+        raise NotImplementedError("doppler.scheme %r: schemes 1 and 2 run on the GPU path; the reference's "
                                   "get_refl kernel is available as cosmo_pol_amd.doppler_c.get_refl" % (scheme,))
-    st = runtime.get_engine(device, doppler=1)
+    st = runtime.get_engine(device, doppler=scheme)
     if lut_sz:
         runtime.ensure_luts(st, lut_sz)
     len_beams = max(len(b.dist_profile) for b in list_beams)

@@ -79,7 +79,7 @@ class RadarOperator(object):
         if self.lut_sz is None:
             raise RuntimeError('lookup tables not set: call set_lut(scheme, lut) first')
         dscheme = cfg.CONFIG['doppler']['scheme']
-        if dscheme not in (1,):
+        if dscheme not in (1, 2):
             raise NotImplementedError('doppler.scheme %r is not available in the batched GPU path' % (dscheme,))
         st = runtime.get_engine(self.device, doppler=dscheme, sensitivity_cut=True)
         runtime.ensure_luts(st, self.lut_sz)

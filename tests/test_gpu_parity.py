@@ -67,10 +67,11 @@ def test_observables_vs_golden(name):
     np.testing.assert_array_equal(mask, g['out_mask'])
 
 
-@pytest.mark.parametrize('scheme,n_gates,n_sub,att', [(1, 667, 1, 1), (1, 667, 9, 1), (2, 500, 9, 1), (2, 300, 27, 0),
-                                                      (2, 1, 1, 1), (2, 65, 3, 1)])
-def test_observables_vs_oracle(scheme, n_gates, n_sub, att):
-    conf = O.make_config(microphysics={'scheme': scheme}, attenuation={'correction': att}, doppler={'scheme': 1},
+@pytest.mark.parametrize('scheme,n_gates,n_sub,att,dscheme', [
+    (1, 667, 1, 1, 1), (1, 667, 9, 1, 1), (2, 500, 9, 1, 1), (2, 300, 27, 0, 1), (2, 1, 1, 1, 1), (2, 65, 3, 1, 1),
+    (1, 667, 9, 1, 2), (1, 130, 1, 0, 2), (2, 200, 9, 1, 2)])
+def test_observables_vs_oracle(scheme, n_gates, n_sub, att, dscheme):
+    conf = O.make_config(microphysics={'scheme': scheme}, attenuation={'correction': att}, doppler={'scheme': dscheme},
                          radar={'radial_resolution': 75. if scheme == 1 else 500., 'frequency': 5.6})
     eng = make_engine(conf)
     beams = syn.synthetic_beams(n_gates, n_sub, scheme, seed=100 + n_gates, res=conf['radar']['radial_resolution'],
@@ -83,6 +84,19 @@ def test_observables_vs_oracle(scheme, n_gates, n_sub, att):
     check_obs(obs, want.values, 'oracle', res_km=conf['radar']['radial_resolution'] / 1000.)
     np.testing.assert_array_equal(mask, want.mask)
     util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+
+
+@pytest.mark.parametrize('ds', [1, 2])
+def test_doppler_vs_golden(ds):
+    """get_doppler_velocity (schemes 1 and 2) against the reference's output."""
+    g = util.golden('doppler_s%d' % ds)
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': ds},
+                         radar={'frequency': 9.41, 'radial_resolution': 75., 'PRI': 700, 'FFT_length': 256})
+    eng = make_engine(conf)
+    beams = util.beams_from_golden(g)
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    util.assert_close(rvel, g['out_RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+    np.testing.assert_array_equal(mask, g['out_mask'])
 
 
 def test_observables_all_invalid():
