@@ -49,12 +49,13 @@ class CpolLut(C.Structure):
 
 class CpolOutputs(C.Structure):
     _fields_ = [('obs', c_float_p), ('rvel', c_double_p), ('mask', c_double_p), ('lat', c_double_p),
-                ('lon', c_double_p), ('dist', c_float_p), ('height', c_float_p), ('ray_status', c_int_p)]
+                ('lon', c_double_p), ('dist', c_float_p), ('height', c_float_p), ('ray_status', c_int_p),
+                ('dspectrum', c_double_p)]
 
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -86,13 +87,14 @@ def load():
                                       c_float_p, c_float_p, c_float_p, c_double_p]
     lib.cpol_upload_lut.argtypes = [vp, C.c_int, C.POINTER(CpolLut), C.POINTER(CpolPsd), C.POINTER(CpolPsd)]
     lib.cpol_set_quadrature.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p]
+    lib.cpol_set_velocity_bins.argtypes = [vp, C.c_int, c_double_p]
     lib.cpol_run_rays.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_run_rays_dev.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_geolocate.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p, c_double_p, c_float_p, c_int_p]
     lib.cpol_interp_points.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_float_p]
     lib.cpol_observables_from_beams.argtypes = [vp, C.c_int, C.c_int, c_float_p, c_float_p, c_double_p,
-                                                c_double_p, c_double_p, c_float_p, c_double_p, c_double_p]
+                                                c_double_p, c_double_p, c_float_p, c_double_p, c_double_p, c_double_p]
     fp, i = c_float_p, C.c_int
     lib.get_all_radar_pts.argtypes = [fp, i, fp, i, i, fp, i, fp, i, i, i, fp, i, i, i, fp, i, fp, i]
     lib.get_all_radar_pts.restype = fp
@@ -131,6 +133,7 @@ class Context(object):
         self.n_sub = 0
         self.var_names = []
         self.doppler = 0
+        self.n_vel = 0
 
     def close(self):
         if self.h:
@@ -229,6 +232,11 @@ class Context(object):
         self._check(self.lib.cpol_upload_lut(self.h, CLASS_INDEX[cls], C.byref(l), C.byref(p), C.byref(pd)),
                     'cpol_upload_lut')
 
+    def set_velocity_bins(self, varray):
+        v = np.ascontiguousarray(varray, dtype=np.float64)
+        self._check(self.lib.cpol_set_velocity_bins(self.h, len(v), dptr(v)), 'cpol_set_velocity_bins')
+        self.n_vel = len(v)
+
     def set_quadrature(self, az_off, el_off, weight):
         a = np.ascontiguousarray(az_off, dtype=np.float64)
         e = np.ascontiguousarray(el_off, dtype=np.float64)
@@ -247,9 +255,11 @@ class Context(object):
                'ray_status': np.zeros(R, dtype=np.int32)}
         if self.doppler:
             out['rvel'] = np.empty((R, G))
+        if self.doppler == 3:
+            out['dspectrum'] = np.empty((R, G, self.n_vel))
         o = CpolOutputs(fptr(out['obs']), dptr(out['rvel']) if self.doppler else None, dptr(out['mask']),
                         dptr(out['lat']), dptr(out['lon']), fptr(out['dist']), fptr(out['height']),
-                        iptr(out['ray_status']))
+                        iptr(out['ray_status']), dptr(out['dspectrum']) if self.doppler == 3 else None)
         rc = self.lib.cpol_run_rays(self.h, R, az.ctypes.data, el.ctypes.data, C.byref(o))
         self._check(rc, 'cpol_run_rays')
         if raise_on_domain and (out['ray_status'] == ERR_DOMAIN).any():
@@ -299,8 +309,11 @@ class Context(object):
         obs = np.empty((N_OBS, G), dtype=np.float32)
         mout = np.empty(G)
         rvel = np.empty(G) if self.doppler else None
+        spec = np.empty((G, self.n_vel)) if self.doppler == 3 else None
         rc = self.lib.cpol_observables_from_beams(self.h, B, G, fptr(vals), fptr(elev), dptr(mask), dptr(weight),
                                                   dptr(az) if az is not None else None, fptr(obs), dptr(mout),
-                                                  dptr(rvel) if rvel is not None else None)
+                                                  dptr(rvel) if rvel is not None else None,
+                                                  dptr(spec) if spec is not None else None)
         self._check(rc, 'cpol_observables_from_beams')
+        self.last_spectrum = spec
         return obs, mout, rvel

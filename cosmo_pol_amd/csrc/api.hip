@@ -128,6 +128,8 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->zcol) hipFree(ctx->zcol);
     if (ctx->dcol) hipFree(ctx->dcol);
     if (ctx->quad_dev) hipFree(ctx->quad_dev);
+    if (ctx->varray_dev) hipFree(ctx->varray_dev);
+    if (ctx->rawptr_dev) hipFree((void *)ctx->rawptr_dev);
     for (auto &l : ctx->lut) {
         float *owned[] = {l.raw, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
         for (float *q : owned) if (q) hipFree(q);
@@ -155,8 +157,11 @@ extern "C" int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg)
     if (!ctx || !cfg) return CPOL_ERR_ARG;
     if (cfg->n_gates <= 0 || cfg->range_res <= 0) return fail(ctx, CPOL_ERR_ARG, "n_gates and range_res must be positive");
     if (cfg->microphysics_scheme != 1 && cfg->microphysics_scheme != 2) return fail(ctx, CPOL_ERR_ARG, "microphysics_scheme must be 1 or 2");
-    if (cfg->doppler_scheme < 0 || cfg->doppler_scheme > 2)
-        return fail(ctx, CPOL_ERR_ARG, "doppler_scheme: 0 (off), 1 and 2 are implemented in the batched path");
+    if (cfg->doppler_scheme < 0 || cfg->doppler_scheme > 3)
+        return fail(ctx, CPOL_ERR_ARG, "doppler_scheme must be 0 (off), 1, 2 or 3");
+    if (cfg->doppler_scheme == 3 && cfg->microphysics_scheme != 1)
+        return fail(ctx, CPOL_ERR_ARG, "doppler_scheme 3 needs 1-moment input: the reference's get_refl handles exactly three "
+                                       "classes (doppler/doppler_c.c:18)");
     ctx->cfg = *cfg;
     if (ctx->cfg.earth_radius == 0) {
         // atm_refraction.py:18-21 evaluated at coords[1] taken as radians (:114-117)
@@ -238,6 +243,17 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
     L.psd = *psd;
     L.psd_dop = psd_doppler ? *psd_doppler : *psd;
     L.present = true;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_set_velocity_bins(cpol_ctx *ctx, int n_vel, const double *varray)
+{
+    if (!ctx || n_vel < 2 || n_vel > 4096 || !varray) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->varray_dev) { HIPCHK(ctx, hipFree(ctx->varray_dev)); ctx->varray_dev = nullptr; }
+    HIPCHK(ctx, hipMalloc((void **)&ctx->varray_dev, n_vel * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(ctx->varray_dev, varray, n_vel * sizeof(double), hipMemcpyDefault));
+    ctx->n_vel = n_vel;
     return CPOL_OK;
 }
 
@@ -351,7 +367,7 @@ static void build_model_view(const cpol_ctx *ctx, ModelView &mv)
 // sub-beam profiles are already on the device.
 static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G, const float *vals, long plane,
                        const float *elev, const signed char *mask, const double *wsub, const double *phi,
-                       float *obs, long obs_plane, long ray0, double *mask_out, double *rvel_out)
+                       float *obs, long obs_plane, long ray0, double *mask_out, double *rvel_out, double *spectrum)
 {
     const long nu = (long)nr * B * G;
     const int n_planes = ct.n_kinds * ct.n_cls;
@@ -371,7 +387,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     {
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
-    launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme,
+    launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
                 (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
                 (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, hist, offs, cursor, chunk_off);
@@ -410,9 +426,29 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         }
     }
     StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
+    if (ctx->cfg.doppler_scheme == 3) {
+        if (ctx->n_vel < 2) return fail(ctx, CPOL_ERR_STATE, "doppler_scheme 3: cpol_set_velocity_bins has not been called");
+        // device array of the raw-table / diameter-axis pointers of the three classes
+        const float *hp[2 * CPOL_MAX_CLASSES] = {nullptr};
+        for (int h = 0; h < 3; h++) { hp[h] = ctx->lut[h].raw; hp[CPOL_MAX_CLASSES + h] = ctx->lut[h].d_axis; }
+        if (!ctx->rawptr_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->rawptr_dev, sizeof(hp)));
+        HIPCHK(ctx, hipMemcpyAsync((void *)ctx->rawptr_dev, hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // hp is a stack buffer
+        SpecParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.n_gates = G; sp.n_sub = B; sp.n_vel = ctx->n_vel; sp.zfac = op.zfac;
+        for (int h = 0; h < 3; h++) {
+            const cpol_psd &pd = ctx->lut[h].psd_dop;
+            sp.d_min[h] = (float)pd.d_min; sp.d_max[h] = (float)pd.d_max; sp.step[h] = ctx->lut[h].dD;
+            sp.inv_alpha[h] = 1.0 / pd.alpha; sp.inv_beta[h] = 1.0 / pd.beta;
+            sp.mu[h] = (float)pd.mu; sp.nu[h] = (float)pd.nu;
+        }
+        launch_spectrum(ctx->stream, ct, sp, nr, nu, vals, plane, elev, mask, wsub, phi, ctx->varray_dev,
+                        ctx->rawptr_dev, ctx->rawptr_dev + CPOL_MAX_CLASSES, spectrum, rvel_out, ray0);
+    }
     launch_observables(ctx->stream, op, nr, nu, (const int *)ctx->b_key.p, (const double *)ctx->b_coef.p,
                        (const float *)ctx->b_psd.p, mask, wsub, (const double *)ctx->b_vr.p, obs, obs_plane, ray0,
-                       mask_out, rvel_out, d2);
+                       mask_out, rvel_out, d2, spectrum, ctx->n_vel);
     HIPCHK(ctx, hipGetLastError());
     return CPOL_OK;
 }
@@ -479,6 +515,10 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
     if (!out->lon) { TRY(ensure(ctx, ctx->o_lon, RG * sizeof(double))); out->lon = (double *)ctx->o_lon.p; }
     if (!out->dist) { TRY(ensure(ctx, ctx->o_dist, RG * sizeof(float))); out->dist = (float *)ctx->o_dist.p; }
     if (!out->height) { TRY(ensure(ctx, ctx->o_height, RG * sizeof(float))); out->height = (float *)ctx->o_height.p; }
+    if (ctx->cfg.doppler_scheme == 3) {
+        if (ctx->n_vel < 2) return fail(ctx, CPOL_ERR_STATE, "doppler_scheme 3: cpol_set_velocity_bins has not been called");
+        if (!out->dspectrum) { TRY(ensure(ctx, ctx->o_spec, (size_t)RG * ctx->n_vel * sizeof(double))); out->dspectrum = (double *)ctx->o_spec.p; }
+    } else out->dspectrum = nullptr;
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->b_status.p, 0, n_rays * sizeof(int), ctx->stream));
@@ -516,7 +556,7 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
         }
         TRY(run_physics(ctx, ct, nr, B, G, (const float *)ctx->b_vals.p, nu_max, (const float *)ctx->b_E.p,
                         (const signed char *)ctx->b_mask.p, wsub, (const double *)ctx->b_phi.p,
-                        out->obs, RG, r0, out->mask, out->rvel));
+                        out->obs, RG, r0, out->mask, out->rvel, out->dspectrum));
     }
     HIPCHK(ctx, hipGetLastError());
     if (!ctx->cfg.doppler_scheme) out->rvel = nullptr;
@@ -537,6 +577,8 @@ extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, c
     hipStream_t s = ctx->stream;
     if (host->obs) HIPCHK(ctx, hipMemcpyAsync(host->obs, d.obs, CPOL_N_OBS * RG * sizeof(float), hipMemcpyDeviceToHost, s));
     if (host->rvel && d.rvel) HIPCHK(ctx, hipMemcpyAsync(host->rvel, d.rvel, RG * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (host->dspectrum && d.dspectrum)
+        HIPCHK(ctx, hipMemcpyAsync(host->dspectrum, d.dspectrum, RG * ctx->n_vel * sizeof(double), hipMemcpyDeviceToHost, s));
     if (host->mask) HIPCHK(ctx, hipMemcpyAsync(host->mask, d.mask, RG * sizeof(double), hipMemcpyDeviceToHost, s));
     if (host->lat) HIPCHK(ctx, hipMemcpyAsync(host->lat, d.lat, RG * sizeof(double), hipMemcpyDeviceToHost, s));
     if (host->lon) HIPCHK(ctx, hipMemcpyAsync(host->lon, d.lon, RG * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -607,7 +649,8 @@ extern "C" int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords_rot,
 
 extern "C" int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates, const float *values,
                                            const float *elev, const double *mask, const double *weight,
-                                           const double *az_sub, float *obs, double *mask_out, double *rvel)
+                                           const double *az_sub, float *obs, double *mask_out, double *rvel,
+                                           double *dspectrum)
 {
     TRY(check_ready(ctx, false, false));
     if (n_sub < 1 || n_gates < 1 || !values || !elev || !mask || !weight) return CPOL_ERR_ARG;
@@ -625,6 +668,7 @@ extern "C" int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates
     TRY(ensure(ctx, ctx->t_c, (size_t)CPOL_N_OBS * n_gates * sizeof(float)));
     TRY(ensure(ctx, ctx->t_d, n_gates * sizeof(double)));
     TRY(ensure(ctx, ctx->t_e, n_gates * sizeof(double)));
+    if (ctx->cfg.doppler_scheme == 3) TRY(ensure(ctx, ctx->o_spec, (size_t)n_gates * (ctx->n_vel > 0 ? ctx->n_vel : 1) * sizeof(double)));
     std::vector<signed char> m8(nu);
     for (long i = 0; i < nu; i++) m8[i] = (signed char)(mask[i] > 0 ? 1 : (mask[i] < 0 ? -1 : 0));
     HIPCHK(ctx, hipMemcpyAsync(ctx->b_vals.p, values, (size_t)CPOL_V_COUNT * nu * sizeof(float), hipMemcpyDefault, s));
@@ -641,12 +685,15 @@ extern "C" int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates
     ctx->cfg.sensitivity_mode = 0;             // get_radar_observables itself applies no cut
     int rc = run_physics(ctx, ct, 1, n_sub, n_gates, (const float *)ctx->b_vals.p, nu, (const float *)ctx->b_E.p,
                          (const signed char *)ctx->b_mask.p, (const double *)ctx->t_a.p, (const double *)ctx->b_phi.p,
-                         (float *)ctx->t_c.p, n_gates, 0, (double *)ctx->t_d.p, (double *)ctx->t_e.p);
+                         (float *)ctx->t_c.p, n_gates, 0, (double *)ctx->t_d.p, (double *)ctx->t_e.p,
+                         ctx->cfg.doppler_scheme == 3 ? (double *)ctx->o_spec.p : nullptr);
     ctx->cfg.sensitivity_mode = save_sens;
     TRY(rc);
     if (obs) HIPCHK(ctx, hipMemcpyAsync(obs, ctx->t_c.p, (size_t)CPOL_N_OBS * n_gates * sizeof(float), hipMemcpyDefault, s));
     if (mask_out) HIPCHK(ctx, hipMemcpyAsync(mask_out, ctx->t_d.p, n_gates * sizeof(double), hipMemcpyDefault, s));
     if (rvel && ctx->cfg.doppler_scheme) HIPCHK(ctx, hipMemcpyAsync(rvel, ctx->t_e.p, n_gates * sizeof(double), hipMemcpyDefault, s));
+    if (dspectrum && ctx->cfg.doppler_scheme == 3)
+        HIPCHK(ctx, hipMemcpyAsync(dspectrum, ctx->o_spec.p, (size_t)n_gates * ctx->n_vel * sizeof(double), hipMemcpyDefault, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return CPOL_OK;
 }

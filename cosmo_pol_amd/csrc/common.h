@@ -97,12 +97,15 @@ struct cpol_ctx {
     int n_sub = 0;
     std::vector<double> az_off, el_off, weight;
     double *quad_dev = nullptr;    // [3][n_sub]: az_off, el_off, weight
+    int n_vel = 0;                 // Doppler spectrum bins (constants.py:75 VARRAY)
+    double *varray_dev = nullptr;
+    const float **rawptr_dev = nullptr;   // [2][CPOL_MAX_CLASSES]: raw tables, diameter axes
     // grow-only device workspaces
     struct Buf { void *p = nullptr; size_t cap = 0; };
     std::vector<Buf *> bufs;
     Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
         b_sorted, b_rank, b_psd, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
-        o_obs, o_rvel, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
+        o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)8 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
     bool timing = false;
@@ -145,6 +148,18 @@ void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *
 void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
+struct SpecParams {
+    int    n_gates, n_sub, n_vel;
+    float  zfac;                   // wavelength^4 / (pi^5 KW^2) as float32
+    float  d_min[3], d_max[3], step[3];
+    double inv_alpha[3], inv_beta[3];   // get_D_from_V: (1/alpha * v)^(1/beta)
+    float  mu[3], nu[3];
+};
+
+void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, int n_rays, long nu, const float *vals,
+                     long plane, const float *elev, const signed char *mask, const double *wsub, const double *phi_sc,
+                     const double *varray, const float *const *raw, const float *const *d_axis, double *spectrum,
+                     double *rvel, long ray0);
 struct Dop2In {                    // inputs of the Doppler scheme-2 reduction inside k_observables
     const float  *vals; long plane;
     const float  *elev;
@@ -159,7 +174,7 @@ struct Dop2In {                    // inputs of the Doppler scheme-2 reduction i
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
-                        long ray0, double *mask_out, double *rvel_out, const Dop2In &d2);
+                        long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel);
 void launch_gather_central(hipStream_t s, int n_rays, int n_sub, int n_gates, const float *S, const float *H,
                            const double *lat, const double *lon, float *dist, float *height, double *olat,
                            double *olon, long ray0);

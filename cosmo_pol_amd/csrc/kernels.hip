@@ -955,7 +955,8 @@ __global__ __launch_bounds__(64)
 void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
-                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2)
+                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2,
+                   double *__restrict__ spectrum, int n_vel)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
     const int G = op.n_gates, B = op.n_sub;
@@ -994,7 +995,7 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
             for (int b = 0; b < B; b++) {
                 long u = ((long)r * B + b) * G + g;
                 msum += (double)mask[u];
-                if (op.doppler) {
+                if (op.doppler == 1 || op.doppler == 2) {
                     double pw = op.doppler == 2 ? doppler2_radial(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
                     double w = wsub[b];
                     sw += (pw != pw) ? 0. : w;
@@ -1037,6 +1038,8 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
             zdr = zh / zv;
         }
         double rvel = rv / sw;
+        bool cut = false;
+        if (op.doppler == 3 && act && rvel_out) rvel = rvel_out[(ray0 + r) * (long)G + g];   // from k_spectrum
         if (op.sens_mode && act) {
             double thr;
             if (op.sens_mode == 1) thr = op.sens0;
@@ -1045,6 +1048,7 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
             if ((double)zdb < thr) {
                 zh = qnan; zv = qnan; phidp = qnan; zdr = qnan; rhohv = qnan; kdpm = qnan;
                 rvel = __builtin_nan("");
+                cut = true;
             }
         }
         if (act) {
@@ -1066,6 +1070,8 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
                 mask_out[o] = m;
             }
             if (rvel_out && op.doppler) rvel_out[o] = rvel;
+            if (cut && spectrum)
+                for (int i = 0; i < n_vel; i++) spectrum[o * n_vel + i] = __builtin_nan("");
         }
     }
 }
@@ -1073,10 +1079,10 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
-                        long ray0, double *mask_out, double *rvel_out, const Dop2In &d2)
+                        long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel)
 {
     hipLaunchKernelGGL(k_observables, dim3(n_rays), dim3(64), 0, s, op, n_rays, nu, key, coef, psd_out, mask,
-                       weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
+                       weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2, spectrum, n_vel);
 }
 
 // geometry of the central sub-beam (scattering_sz.py:154-157)
@@ -1134,4 +1140,133 @@ void launch_get_refl(hipStream_t s, float *refl, int nbins, const float *Da, con
 {
     hipLaunchKernelGGL(k_get_refl, dim3((nbins + 63) / 64), dim3(64), 0, s, refl, nbins, Da, Db, D, rcs, N0, mu, lam,
                        nu, step, dmin);
+}
+
+// =============================================================================
+// Doppler scheme 3: full Doppler spectrum (doppler_sz.py:233-306,337-367 and
+// doppler_c.c:11-33).  One wavefront per (ray, gate); it walks the sub-beams, and for
+// each: (1) the lanes evaluate the 3 x 1024 terms D^mu exp(-lambda D^nu) rcs in float64
+// into LDS, (2) one lane per velocity bin converts the bin's fall-speed interval into a
+// diameter interval per class and sums its terms with the reference's float accumulator,
+// (3) the GH-weighted bin values are accumulated in float64.  Three classes (rain, snow,
+// graupel), as the reference's get_refl hard-wires.
+// =============================================================================
+__global__ __launch_bounds__(64)
+void k_spectrum(ClassTable ct, SpecParams sp, long nu_, const float *__restrict__ vals, long plane,
+                const float *__restrict__ elev, const signed char *__restrict__ mask, const double *__restrict__ wsub,
+                const double *__restrict__ phi_sc, const double *__restrict__ varray,
+                const float *const *__restrict__ raw, const float *const *__restrict__ d_axis,
+                double *__restrict__ spectrum, double *__restrict__ rvel, long ray0)
+{
+    extern __shared__ double sm[];
+    double *term = sm;                       // [3][1024]
+    double *acc = sm + 3 * 1024;             // [n_vel]
+    const int lane = threadIdx.x;
+    const int G = sp.n_gates, B = sp.n_sub, NV = sp.n_vel;
+    const int r = blockIdx.x / G, g = blockIdx.x % G;
+    for (int i = lane; i < NV; i += 64) acc[i] = 0.;
+    __syncthreads();
+    for (int b = 0; b < B; b++) {
+        const long rb = (long)r * B + b;
+        const long u = rb * G + g;
+        if (mask[u] != 0) continue;                       // wave-uniform (doppler_sz.py:271)
+        const float T = vals[(long)CPOL_V_T * plane + u];
+        const float e_raw = elev[u];
+        const float e_lut = fold_elev(e_raw);
+        float lam32[3], n032[3];
+        for (int jc = 0; jc < 3; jc++) {
+            const PsdView &p = ct.dop[jc];
+            float q = vals[(long)p.q_var * plane + u];
+            float Tp = vals[(long)p.t_var * plane + u];
+            double l, n0;
+            psd_params(p, q, 0.f, Tp, &l, &n0);
+            if (q == 0.f) l = __builtin_nan("");
+            lam32[jc] = (float)l; n032[jc] = (float)n0;
+            // terms of the class at the table node nearest to (elevation, temperature)
+            const LutView &lv = ct.lut[jc];
+            int ie = nearest_node(e_lut, lv.e_min, lv.e_step, lv.n_e);
+            int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
+            const float *sl = raw[jc] + (long)(ie * lv.n_t + it) * 1024 * CPOL_N_SZ;
+            const bool on = lam32[jc] > 0.f;
+            for (int k = lane; k < 1024; k += 64) {
+                double t = 0.;
+                if (on) {
+                    float4 z = *(const float4 *)(sl + k * CPOL_N_SZ);
+                    float rcs = (float)(2 * M_PI) * (((z.x - z.y) - z.z) + z.w);
+                    double D = (double)d_axis[jc][k];
+                    double dm = sp.mu[jc] == 0.f ? 1. : (sp.mu[jc] == 1.f ? D : pow(D, (double)sp.mu[jc]));
+                    double dn = sp.nu[jc] == 1.f ? D : pow(D, (double)sp.nu[jc]);
+                    t = dm * exp(-(double)lam32[jc] * dn) * (double)rcs;
+                }
+                term[jc * 1024 + k] = t;
+            }
+        }
+        __syncthreads();
+        // fall speed at the velocity bins (doppler_sz.py:337-346), NumPy promotion kept
+        const float rho = vals[(long)CPOL_V_RHO * plane + u], rho0 = vals[(long)CPOL_V_RHO * plane + rb * G];
+        const float rinv = 1.0f / sqrtf(rho / rho0);
+        const float th = e_raw * (float)(M_PI / 180.0);
+        const double Uw = vals[(long)CPOL_V_U * plane + u], Vw = vals[(long)CPOL_V_V * plane + u];
+        const double Ww = vals[(long)CPOL_V_W * plane + u];
+        // float32 sin/tan as the correctly rounded value: v/sin(theta) cancels against the wind term to a few
+        // m/s out of hundreds at low elevation, so the last bit of these two decides which table term falls in
+        // which velocity bin; the reference's result there depends on its libm in the same way
+        const double hor = (Uw * phi_sc[2 * rb] + Vw * phi_sc[2 * rb + 1]) / (double)(float)tan((double)th);
+        const double sth = (double)(float)sin((double)th);
+        const double w = wsub[b];
+        for (int i = lane; i < NV - 1; i += 64) {
+            double wh0 = (double)rinv * (Ww + hor - varray[i] / sth);
+            double wh1 = (double)rinv * (Ww + hor - varray[i + 1] / sth);
+            if (!(wh0 >= 0) || !(wh1 >= 0)) continue;
+            float Da[3], Db[3];
+            bool keep = false;
+            for (int jc = 0; jc < 3; jc++) {
+                float d0 = (float)pow(sp.inv_alpha[jc] * wh0, sp.inv_beta[jc]);
+                float d1 = (float)pow(sp.inv_alpha[jc] * wh1, sp.inv_beta[jc]);
+                // the reference clips the whole matrix with each later class's limits (:355-357)
+                for (int jl = jc; jl < 3; jl++) {
+                    if (d0 >= sp.d_max[jl]) d0 = sp.d_max[jl];
+                    if (d0 <= sp.d_min[jl]) d0 = sp.d_min[jl];
+                    if (d1 >= sp.d_max[jl]) d1 = sp.d_max[jl];
+                    if (d1 <= sp.d_min[jl]) d1 = sp.d_min[jl];
+                }
+                Da[jc] = fminf(d0, d1); Db[jc] = fmaxf(d0, d1);
+                keep = keep || (Db[jc] - Da[jc]) != 0.0f;
+            }
+            if (!keep) continue;
+            float refl = 0.f;
+            for (int jc = 0; jc < 3; jc++) {
+                if (lam32[jc] > 0.f) {
+                    int ia = (int)((Da[jc] - sp.d_min[jc]) / sp.step[jc]);
+                    int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
+                    float sum = 0.f;
+                    for (int k = ia; k < ib; k++) sum = (float)((double)sum + term[jc * 1024 + k]);
+                    refl += sum * sp.step[jc] * n032[jc];
+                }
+            }
+            refl *= sp.zfac;
+            acc[i] += (double)refl * w;
+        }
+        __syncthreads();
+    }
+    // spectrum and its first moment (doppler_sz.py:99)
+    double s0 = 0., s1 = 0.;
+    const long o = ((ray0 + r) * (long)G + g);
+    for (int i = lane; i < NV; i += 64) {
+        double a = acc[i];
+        if (spectrum) spectrum[o * NV + i] = a;
+        s0 += a; s1 += varray[i] * a;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    if (lane == 0 && rvel) rvel[o] = s1 / s0;
+}
+
+void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, int n_rays, long nu, const float *vals,
+                     long plane, const float *elev, const signed char *mask, const double *wsub, const double *phi_sc,
+                     const double *varray, const float *const *raw, const float *const *d_axis, double *spectrum,
+                     double *rvel, long ray0)
+{
+    size_t lds = (size_t)(3 * 1024 + sp.n_vel) * sizeof(double);
+    hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((long)n_rays * sp.n_gates)), dim3(64), lds, s, ct, sp, nu, vals, plane,
+                       elev, mask, wsub, phi_sc, varray, raw, d_axis, spectrum, rvel, ray0);
 }

@@ -1,6 +1,7 @@
 """get_doppler_velocity with the reference signature (doppler/doppler_sz.py:26).  Scheme 1 (PSD-weighted fall
-speed, closed form) and scheme 2 (RCS- and PSD-weighted, two extra columns of the PSD integration) run in the
-HIP kernels; scheme 3 (full spectrum) is not part of the batched path yet and raises."""
+speed, closed form), scheme 2 (RCS- and PSD-weighted, two extra columns of the PSD integration) and scheme 3
+(full Doppler spectrum, one wavefront per gate; 1-moment input only, as the reference's get_refl handles three
+classes) all run in the HIP kernels."""
 import numpy as np
 
 from . import cfg, runtime
@@ -10,9 +11,8 @@ from .scattering_sz import _pack
 
 def get_doppler_velocity(list_beams, lut_sz=0, device=0):
     scheme = cfg.CONFIG['doppler']['scheme']
-    if scheme not in (1, 2):
-        raise NotImplementedError("doppler.scheme %r: schemes 1 and 2 run on the GPU path; the reference's "
-                                  "get_refl kernel is available as cosmo_pol_amd.doppler_c.get_refl" % (scheme,))
+    if scheme not in (1, 2, 3):
+        raise ValueError("doppler.scheme must be 1, 2 or 3, got %r" % (scheme,))
     st = runtime.get_engine(device, doppler=scheme)
     if lut_sz:
         runtime.ensure_luts(st, lut_sz)
@@ -21,4 +21,7 @@ def get_doppler_velocity(list_beams, lut_sz=0, device=0):
     az = np.array([b.GH_pt[0] for b in list_beams], dtype=np.float64)
     _, mask_out, rvel = st.eng.ctx.observables_from_beams(vals, elev, mask, w, az)
     c = list_beams[int(len(list_beams) / 2)]
-    return Beam({'RVEL': rvel}, mask_out, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)
+    vals_out = {'RVEL': rvel}
+    if scheme == 3:
+        vals_out['DSPECTRUM'] = st.eng.ctx.last_spectrum                 # doppler_sz.py:123
+    return Beam(vals_out, mask_out, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)

@@ -72,6 +72,11 @@ class Engine(object):
                             microphysics_scheme=int(conf['microphysics']['scheme']),
                             doppler_scheme=int(dscheme), sensitivity_mode=mode,
                             sensitivity=(float(sens[0]), float(sens[1]) if len(sens) > 1 else 0.))
+        if int(dscheme) == 3:
+            nvel = cst.C / (4 * 1E-6 * r['PRI'] * r['frequency'] * 1E09)
+            vres = 2 * nvel / r['FFT_length']
+            self.varray = np.arange(-nvel, nvel + vres, vres)                    # constants.py:73-75
+            self.ctx.set_velocity_bins(self.varray)
         self.conf = conf
         self.n_gates = len(rr)
 

@@ -79,8 +79,8 @@ class RadarOperator(object):
         if self.lut_sz is None:
             raise RuntimeError('lookup tables not set: call set_lut(scheme, lut) first')
         dscheme = cfg.CONFIG['doppler']['scheme']
-        if dscheme not in (1, 2):
-            raise NotImplementedError('doppler.scheme %r is not available in the batched GPU path' % (dscheme,))
+        if dscheme not in (1, 2, 3):
+            raise ValueError('doppler.scheme must be 1, 2 or 3, got %r' % (dscheme,))
         st = runtime.get_engine(self.device, doppler=dscheme, sensitivity_cut=True)
         runtime.ensure_luts(st, self.lut_sz)
         runtime.ensure_model(st, self.dic_vars)
@@ -96,6 +96,8 @@ class RadarOperator(object):
         out = ctx.run_rays(azs[idx], els[idx])      # raises IndexError when a gate leaves the model domain
         fields = {n: out['obs'][i] for i, n in enumerate(OBS_NAMES)}
         fields['RVEL'] = out['rvel']
+        if dscheme == 3:
+            fields['DSPECTRUM'] = out['dspectrum']              # [n_rays, n_gates, n_velocity_bins]
         extra = {'mask': out['mask'], 'lat': out['lat'], 'lon': out['lon'], 'height': out['height']}
         if world > 1:
             import torch

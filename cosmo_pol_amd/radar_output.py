@@ -4,8 +4,9 @@
 import numpy as np
 
 UNITS = {'ZH': 'dBZ', 'ZV': 'dBZ', 'ZDR': 'dB', 'KDP': 'deg/km', 'PHIDP': 'deg', 'RHOHV': '-', 'RVEL': 'm/s',
-         'DELTA_HV': 'rad', 'AH': 'dB/km', 'AV': 'dB/km'}
-DB_FIELDS = ('ZDR', 'ZV', 'ZH')
+         'DELTA_HV': 'rad', 'AH': 'dB/km', 'AV': 'dB/km', 'DSPECTRUM': 'dBZ'}
+DB_FIELDS = ('ZDR', 'ZV', 'ZH')        # the reference's list also names 'DSpectrum', which matches no key: the
+                                        # spectrum stays linear (pyart_wrapper.py:159)
 
 
 class SimulatedRadar(object):

@@ -55,7 +55,7 @@ typedef struct {
     double kw;                                /* constants.KW */
     int    attenuation_correction;            /* attenuation.correction */
     int    microphysics_scheme;               /* 1 or 2 */
-    int    doppler_scheme;                    /* 0 = skip, 1, 2 (3: see cpol_doppler_spectrum) */
+    int    doppler_scheme;                    /* 0 = skip, 1, 2, 3 (3 needs cpol_set_velocity_bins and 1-moment input) */
     int    sensitivity_mode;                  /* 0 = no cut, 1 = scalar, 2 = [ZH, range] (utilities.py:74-81) */
     double sensitivity[2];
 } cpol_config;
@@ -128,6 +128,10 @@ int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, const float 
 int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,
                     const cpol_psd *psd_doppler);
 
+/* Velocity bins of the Doppler spectrum: constants.VARRAY = arange(-NVEL, NVEL + VRES, VRES)
+ * (constants/constants.py:73-75).  Needed for doppler_scheme 3. */
+int cpol_set_velocity_bins(cpol_ctx *ctx, int n_vel, const double *varray);
+
 /* Antenna quadrature: the kept sub-beams of interpolation/interpolation.py:260-279 in
  * reference order, as offsets (degrees) added to the ray's azimuth / elevation and
  * normalised weights.  The central sub-beam is index n_sub/2 (scattering_sz.py:25). */
@@ -155,6 +159,7 @@ typedef struct {
     double *lat, *lon;
     float  *dist, *height;
     int    *ray_status;
+    double *dspectrum;      /* float64 [n_rays][n_gates][n_vel], doppler_scheme 3 only (doppler_sz.py:91-97) */
 } cpol_outputs;
 
 int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
@@ -180,11 +185,13 @@ int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords_rot, const floa
  * i.e. on the list[Beam] that get_profiles_GH returns.  values is [CPOL_V_COUNT][n_sub][n_gates]
  * (slots that the scheme does not use are ignored), elev/mask are [n_sub][n_gates], weight
  * [n_sub].  obs float32 [CPOL_N_OBS][n_gates], mask_out float64 [n_gates].
- * With doppler_scheme 1 or 2, rvel float64 [n_gates] receives doppler_sz.py:26
- * (get_doppler_velocity); az_sub [n_sub] is GH_pt[0] of each sub-beam. */
+ * With doppler_scheme 1, 2 or 3, rvel float64 [n_gates] receives doppler_sz.py:26
+ * (get_doppler_velocity); az_sub [n_sub] is GH_pt[0] of each sub-beam.  With scheme 3,
+ * dspectrum float64 [n_gates][n_vel] (may be NULL) receives the Doppler spectrum. */
 int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates, const float *values,
                                 const float *elev, const double *mask, const double *weight,
-                                const double *az_sub, float *obs, double *mask_out, double *rvel);
+                                const double *az_sub, float *obs, double *mask_out, double *rvel,
+                                double *dspectrum);
 
 /* ---- drop-in replacements of the reference's SWIG/C symbols --------------------------- */
 /* interpolation/interpolation_c.c:8,12 -- identical signature; runs on device 0 through a

@@ -86,9 +86,9 @@ def test_observables_vs_oracle(scheme, n_gates, n_sub, att, dscheme):
     util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
 
 
-@pytest.mark.parametrize('ds', [1, 2])
+@pytest.mark.parametrize('ds', [1, 2, 3])
 def test_doppler_vs_golden(ds):
-    """get_doppler_velocity (schemes 1 and 2) against the reference's output."""
+    """get_doppler_velocity (schemes 1, 2 and 3) against the reference's output."""
     g = util.golden('doppler_s%d' % ds)
     conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': ds},
                          radar={'frequency': 9.41, 'radial_resolution': 75., 'PRI': 700, 'FFT_length': 256})
@@ -97,6 +97,55 @@ def test_doppler_vs_golden(ds):
     obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
     util.assert_close(rvel, g['out_RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
     np.testing.assert_array_equal(mask, g['out_mask'])
+    if ds == 3:
+        np.testing.assert_allclose(eng.varray, g['varray'], rtol=0, atol=0)
+        check_spectrum(eng.ctx.last_spectrum, g['out_DSPECTRUM'])
+
+
+def check_spectrum(got, want, n_edge=0):
+    """Every bin is a float32 sum of float64 terms (doppler_c.c:24-26) scaled and GH-weighted: same zero pattern,
+    and values to a few float32 ulps of the gate's largest bin.
+
+    n_edge > 0 (low elevations): the fall speed of a bin edge is W + wind/tan(el) - v/sin(el) evaluated with
+    float32 sin and tan (doppler_sz.py:341), a few m/s left over from hundreds, so one ulp of sin or tan moves an
+    edge by 1e-5 relative and with it one table term from one bin to the next.  NumPy's float32 sin / tan are
+    not correctly rounded (5 % / 25 % of arguments differ from the rounded exact value on AVX512), so the
+    reference's own output changes with the CPU it runs on; up to n_edge bins per gate may then differ by one
+    term (a few percent of the gate's peak)."""
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got == 0, want == 0)
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    bad = np.abs(got - want) > 2e-6 * np.abs(want) + 1e-6 * peak
+    if n_edge:
+        assert bad.sum(axis=1).max() <= n_edge and bad.mean() < 0.01
+        assert np.all(np.abs(got - want)[bad] <= 0.05 * np.broadcast_to(peak, want.shape)[bad])
+        return int(bad.sum())
+    assert not bad.any(), "%d bins differ, first %s: got %r want %r (gate peak %r)" % (
+        bad.sum(), np.argwhere(bad)[0], got[bad][0], want[bad][0], peak[np.argwhere(bad)[0][0], 0])
+    return 0
+
+
+@pytest.mark.parametrize('n_gates,n_sub', [(40, 1), (24, 9)])
+def test_doppler_spectrum_vs_oracle(n_gates, n_sub):
+    """Scheme 3 on other seeds / sub-beam counts against the CPU restatement, with the observables alongside."""
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': 3},
+                         radar={'frequency': 5.6, 'radial_resolution': 250., 'PRI': 1000, 'FFT_length': 128})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(n_gates, n_sub, 1, seed=77 + n_sub, res=250., elevation=12.0, nan_tail=4, below_head=2)
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    luts = util.oracle_luts(1, 5.6)
+    with np.errstate(all='ignore'):
+        want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf, get_refl=O.get_refl_c)
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
+    check_obs(obs, want.values, 'oracle', res_km=0.25)
+    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+    check_spectrum(eng.ctx.last_spectrum, want_v.values['DSPECTRUM'])
+
+
+def test_doppler_scheme3_needs_one_moment():
+    conf = O.make_config(microphysics={'scheme': 2}, doppler={'scheme': 3})
+    with pytest.raises(RuntimeError):
+        engine.Engine(conf, device=0)
 
 
 def test_observables_all_invalid():
@@ -355,3 +404,35 @@ def test_radar_operator_ppi_with_sensitivity_cut():
             rv = radar.get_field(s, 'RVEL')[i].filled(np.nan)
             util.assert_close(rv, b.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
     assert cut > 0          # the cut was exercised
+
+
+def test_radar_operator_rhi_doppler_spectrum():
+    """get_RHI with doppler.scheme 3: RVEL and DSPECTRUM per ray, rows removed by the sensitivity cut are NaN."""
+    from cosmo_pol_amd import RadarOperator
+    conf, m, dic, luts = _api_setup(1, 1, 3, dscheme=3, sens=[5, 10000])
+    op = RadarOperator(conf)
+    op.load_model_file(dic)
+    op.set_lut(1, luts)
+    els = [3.0, 12.0, 35.0]
+    radar = op.get_RHI(77.0, elevations=els)
+    spec = radar.fields['DSPECTRUM']['data']
+    assert spec.shape[:2] == (3, 40)
+    olut = util.oracle_luts(1, 5.6)
+    cut = 0
+    for i, el in enumerate(els):
+        with np.errstate(all='ignore'):
+            beams = O.get_profiles_GH(oracle_model_vars(m), 77.0, el, conf)
+            v = O.get_doppler_velocity(beams, olut, conf, get_refl=O.get_refl_c)
+            b = O.get_radar_observables(beams, olut, conf)
+            b.values.update(v.values)
+            pre = np.isfinite(b.values['ZH']).sum()
+            O.cut_at_sensitivity([b], conf)
+            cut += pre - np.isfinite(b.values['ZH']).sum()
+        want = b.values['DSPECTRUM']
+        got = spec[i].filled(np.nan)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want).any(axis=1)
+        n_moved = check_spectrum(got[ok], want[ok], n_edge=2 if el < 8 else 0)
+        rv = radar.get_field(0, 'RVEL')[i].filled(np.nan)
+        util.assert_close(rv, b.values['RVEL'], rtol=1e-5, atol=0.05 if n_moved else 1e-6, name='RVEL')
+    assert cut > 0
