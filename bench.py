@@ -4,7 +4,8 @@
 Workload (BASELINE.json configs[3], "CH_PPI_lema"): one C-band PPI volume of 20 elevations x
 360 azimuths x 500 gates on a COSMO-1-shaped model grid (80 x 774 x 1158), 2-moment
 microphysics (4 hydrometeor classes), 3 x 3 Gauss-Hermite antenna quadrature (9 sub-beams per
-gate), attenuation correction on, Doppler scheme 1.  Synthetic model state and synthetic
+gate), attenuation correction on, Doppler scheme 2 (RCS-weighted fall speed; `--doppler 1` selects the
+closed-form scheme the reference's CH_PPI_lema.yml names).  Synthetic model state and synthetic
 lookup tables (cosmo_pol_amd/synthetic.py).  One step = one whole volume: geolocation ->
 trilinear interpolation -> PSD set-up / bucket sort -> PSD integration -> per-ray scans, all
 inputs and outputs resident in HBM.
@@ -34,15 +35,16 @@ ELEVATIONS = [-0.2, 0.4, 1, 1.6, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 8.5, 9.5, 11, 13,
 PEAK_F32_MFMA_TFLOPS = 157.3      # dense f32-input MFMA peak of MI355X
 N_D = 1024
 FLOP_PER_UNIT = 27 * N_D          # 12 components x (mul + add) + 3 for N(D), per diameter bin
+FLOP_PER_UNIT_DOP2 = 6 * N_D      # Doppler scheme 2: two more columns (N rcs, N v rcs), mul + add + weight each
 
 
-def workload_config(small=False):
+def workload_config(small=False, doppler=2):
     from cosmo_pol_amd import cfg
     conf = {'radar': {'coords': [46.04079, 8.83321, 1604], 'type': 'ground', 'frequency': 5.6,
                       'range': 250000, 'radial_resolution': 500, 'PRI': 700, 'FFT_length': 128,
                       'sensitivity': [-15, 10000], '3dB_beamwidth': 1.},
             'integration': {'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.},
-            'refraction': {'scheme': 1}, 'attenuation': {'correction': 1}, 'doppler': {'scheme': 1},
+            'refraction': {'scheme': 1}, 'attenuation': {'correction': 1}, 'doppler': {'scheme': doppler},
             'microphysics': {'scheme': 2}}
     if small:
         conf['radar']['range'] = 50000
@@ -108,6 +110,7 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=1440)
     ap.add_argument('--cpu-cores', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--doppler', type=int, choices=[0, 1, 2], default=2, help='doppler.scheme of the workload')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
     args = ap.parse_args()
 
@@ -116,7 +119,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
     from cosmo_pol_amd import synthetic as syn
-    conf = workload_config(args.small)
+    conf = workload_config(args.small, args.doppler)
     azs, elv = volume_rays(args.small)
     shape = (80, 774, 1158) if not args.small else (24, 200, 240)
     model = syn.synthetic_model(*shape, scheme=2, seed=20161111 + (rank if args.scaling == 'weak' else 0),
@@ -204,7 +207,10 @@ def main():
     if rank == 0:
         gates_per_step = (len(azs) * G) * (world if args.scaling == 'weak' else 1)
         ms_int = tim['ms']['integrate'] / max(1, tim['launches']['integrate'])
-        flop_per_launch = FLOP_PER_UNIT * tim['valid_units'] / max(1, tim['launches']['integrate'])
+        # the two Doppler scheme-2 columns count for k_integrate only when they ride on its units; with
+        # 2-moment input they are units of their own on the vector ALUs (stage integrate_dop)
+        flop_unit = FLOP_PER_UNIT + (FLOP_PER_UNIT_DOP2 if args.doppler == 2 and tim['doppler_units'] == 0 else 0)
+        flop_per_launch = flop_unit * tim['valid_units'] / max(1, tim['launches']['integrate'])
         achieved = flop_per_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -217,16 +223,17 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'CH_PPI_lema volume: 20 elevations x 360 azimuths x %d gates, COSMO-1 grid '
                                    '%dx%dx%d, 2-moment (4 classes), 3x3 Gauss-Hermite (9 sub-beams), attenuation on, '
-                                   'Doppler scheme 1%s' % (G, shape[2], shape[1], shape[0],
-                                                           ' [SMALL DEBUG RUN - INVALID]' if args.small else ''),
+                                   'Doppler scheme %d%s' % (G, shape[2], shape[1], shape[0], args.doppler,
+                                                            ' [SMALL DEBUG RUN - INVALID]' if args.small else ''),
                        'rays_per_rank': R, 'gates': G, 'sub_beams': eng.ctx.n_sub, 'classes': 4,
                        'parallelism': 'rays sharded, %d rank(s)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_integrate', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch,
+                         'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
                          'launches': tim['launches']['integrate']},
             'stage_ms_per_step': {k: v / args.steps for k, v in tim['ms'].items()},
             'valid_units_per_step': tim['valid_units'] / args.steps,
+            'doppler_units_per_step': tim['doppler_units'] / args.steps,
             'finite_zh_fraction': finite,
             'cpu_baseline': cpu,
         }

@@ -80,7 +80,7 @@ def load():
     lib.cpol_stream.restype = vp
     lib.cpol_synchronize.argtypes = [vp]
     lib.cpol_timing_enable.argtypes = [vp, C.c_int]
-    lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p]
+    lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
@@ -162,18 +162,18 @@ class Context(object):
     def synchronize(self):
         self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
 
-    STAGES = ['geom', 'interp', 'prep_sort', 'integrate', 'observables']
+    STAGES = ['geom', 'interp', 'prep_sort', 'integrate', 'observables', 'integrate_dop']
 
     def timing_enable(self, on=True):
         self._check(self.lib.cpol_timing_enable(self.h, int(on)), 'cpol_timing_enable')
 
     def timing_read(self):
-        ms = (C.c_double * 5)()
-        nl = (C.c_long * 5)()
-        vu = C.c_double()
-        self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu)), 'cpol_timing_read')
+        ms = (C.c_double * len(self.STAGES))()
+        nl = (C.c_long * len(self.STAGES))()
+        vu, du = C.c_double(), C.c_double()
+        self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu), C.byref(du)), 'cpol_timing_read')
         return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
-                'valid_units': vu.value}
+                'valid_units': vu.value, 'doppler_units': du.value}
 
     def set_batch_units(self, n):
         self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')

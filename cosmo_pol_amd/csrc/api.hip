@@ -60,7 +60,10 @@ static void timing_collect(cpol_ctx *ctx)
     }
     ctx->spans.clear();
     ctx->ev_used = 0;
-    for (size_t i = 0; i < ctx->valid_used; i++) ctx->valid_units += ctx->valid_host[i];
+    for (size_t i = 0; i < ctx->valid_used; i++) {
+        ctx->valid_units += ctx->valid_host[2 * i];
+        ctx->dop_units += ctx->valid_host[2 * i + 1] - ctx->valid_host[2 * i];
+    }
     ctx->valid_used = 0;
 }
 
@@ -72,12 +75,12 @@ extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
     timing_collect(ctx);
     ctx->timing = on != 0;
     for (int i = 0; i < CPOL_N_STAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_launches[i] = 0; }
-    ctx->valid_units = 0;
+    ctx->valid_units = 0; ctx->dop_units = 0;
     return CPOL_OK;
 }
 
 extern "C" int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_launches[CPOL_N_STAGES],
-                                double *valid_units)
+                                double *valid_units, double *doppler_units)
 {
     if (!ctx) return CPOL_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -88,6 +91,7 @@ extern "C" int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], l
         if (stage_launches) stage_launches[i] = ctx->stage_launches[i];
     }
     if (valid_units) *valid_units = ctx->valid_units;
+    if (doppler_units) *doppler_units = ctx->dop_units;
     return CPOL_OK;
 }
 
@@ -290,13 +294,13 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
     memset(&ct, 0, sizeof(ct));
     ct.n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
     const bool dop2 = ctx->cfg.doppler_scheme == 2;
-    ct.ncol = dop2 ? 14 : 12;
     bool shared = dop2;
     for (int h = 0; h < ct.n_cls; h++) {
         if (!ctx->lut[h].present) return fail(ctx, CPOL_ERR_STATE, "a lookup table of the microphysics scheme is missing");
         shared = shared && same_psd(ctx->lut[h].psd, ctx->lut[h].psd_dop);
     }
     ct.dop_shared = shared ? 1 : 0;
+    ct.ncol = shared ? 14 : 12;
     ct.n_kinds = (dop2 && !shared) ? 2 : 1;
     for (int h = 0; h < ct.n_cls; h++) {
         LutDev &L = ctx->lut[h];
@@ -313,9 +317,9 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
             launch_build_image(ctx->stream, L.raw, L.d_axis, L.table, L.xq, nslice, ct.ncol, L.psd.mu, L.psd.nu,
                                shared ? 1 : 0, 0, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta);
             if (want_dop_img) {
-                HIPCHK(ctx, hipMalloc((void **)&L.table_dop, img_bytes));
-                launch_build_image(ctx->stream, L.raw, L.d_axis, L.table_dop, L.xq_dop, nslice, ct.ncol, L.psd_dop.mu,
-                                   L.psd_dop.nu, 1, 1, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta);
+                HIPCHK(ctx, hipMalloc((void **)&L.table_dop, (size_t)nslice * CPOL_DOP_SLICE * sizeof(float)));
+                launch_build_dop_image(ctx->stream, L.raw, L.d_axis, L.table_dop, L.xq_dop, nslice, L.psd_dop.mu,
+                                       L.psd_dop.nu, L.psd_dop.alpha, L.psd_dop.beta);
             }
             HIPCHK(ctx, hipGetLastError());
             L.image_ncol = tag;
@@ -373,6 +377,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const int n_planes = ct.n_kinds * ct.n_cls;
     const long nslots = nu * n_planes;
     const int nb = n_planes * ct.ne_max * ct.nt_max;
+    const int nb_pol = ct.n_cls * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
     TRY(ensure(ctx, ctx->b_key, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
@@ -400,17 +405,25 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             timing_collect(ctx);
             if (!ctx->valid_host) {
-                HIPCHK(ctx, hipHostMalloc((void **)&ctx->valid_host, 4096 * sizeof(int), hipHostMallocDefault));
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->valid_host, 2 * 4096 * sizeof(int), hipHostMallocDefault));
                 ctx->valid_cap = 4096;
             }
         }
-        HIPCHK(ctx, hipMemcpyAsync(ctx->valid_host + ctx->valid_used++, offs + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        int *vh = ctx->valid_host + 2 * ctx->valid_used++;
+        HIPCHK(ctx, hipMemcpyAsync(vh, offs + nb_pol, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(vh + 1, offs + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
-    long max_chunks = (nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb;
+    // upper bound of the chunk count of either kind (the exact count lives on the device)
+    const long max_chunks = (nu * ct.n_cls + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb_pol;
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
-    launch_integrate(ctx->stream, ct, max_chunks, nb, offs, chunk_off, (const int *)ctx->b_sorted.p,
+    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_sorted.p,
                      (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
+    }
+    if (ct.n_kinds == 2) {
+        StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
+        launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->b_sorted.p,
+                             (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
@@ -419,7 +432,16 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     if (ctx->cfg.doppler_scheme == 2) {
         d2.vals = vals; d2.plane = plane; d2.elev = elev; d2.phi_sc = phi;
         d2.lam = (const float2 *)ctx->b_lam.p; d2.n0d = (const double *)ctx->b_n0d.p;
-        d2.n_cls = ct.n_cls; d2.ne_max = ct.ne_max; d2.nt_max = ct.nt_max; d2.ncol = ct.ncol; d2.shared = ct.dop_shared;
+        d2.n_cls = ct.n_cls; d2.ne_max = ct.ne_max; d2.nt_max = ct.nt_max; d2.shared = ct.dop_shared;
+        if (ct.dop_shared) {       // columns 12, 13 of the 14-column image; d = 1023 is (q, k, s) = (63, 3, 3)
+            d2.slice_floats = 1024 * 14;
+            d2.at0[0] = 12 * 4; d2.at0[1] = 13 * 4;
+            d2.at1[0] = (((63 * 4 + 3) * 14 + 12) << 2) + 3; d2.at1[1] = (((63 * 4 + 3) * 14 + 13) << 2) + 3;
+        } else {                   // words 1, 2 of the compact image
+            d2.slice_floats = CPOL_DOP_SLICE;
+            d2.at0[0] = 4; d2.at0[1] = 8;
+            d2.at1[0] = (63 * 4 + 3) * 12 + 4 + 3; d2.at1[1] = (63 * 4 + 3) * 12 + 8 + 3;
+        }
         for (int h = 0; h < ct.n_cls; h++) {
             const LutView &v = ct.dop_shared ? ct.lut[h] : ct.lut_dop[h];
             d2.img[h] = v.table; d2.xq[h] = v.xq; d2.n_t[h] = v.n_t;

@@ -9,6 +9,7 @@
 #define CPOL_WAVE 64
 #define CPOL_CHUNK_UNITS 256      // units (gate x sub-beam x class) per integrate workgroup
 #define CPOL_SORT_SHARDS 16         // counters per bucket: spreads same-address atomics of big buckets
+#define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_N_COL 16             // MFMA N dimension: 12 scattering components + 4 spare columns
 
 struct LutDev {
@@ -19,7 +20,7 @@ struct LutDev {
     float *raw = nullptr;          // [n_e][n_t][1024][12] as uploaded
     float *table = nullptr;        // [n_e][n_t] slices of 1024 x ncol, permuted and pre-multiplied by D^mu (see k_integrate)
     float *xq = nullptr;           // D^nu, permuted for the integrate kernel's ds_read_b128
-    float *table_dop = nullptr;    // same for the separate Doppler units (2-moment input + doppler scheme 2)
+    float *table_dop = nullptr;    // compact 3-column image of the separate Doppler units (k_integrate_dop)
     float *xq_dop = nullptr;
     float *d_axis = nullptr;       // [n_d]
     int    image_ncol = 0;         // what `table` was last built for
@@ -47,7 +48,8 @@ struct ClassTable {
     int     n_cls;
     int     ne_max, nt_max;        // bucket id = ((kind*n_cls + cls)*ne_max + ie)*nt_max + it
     int     n_kinds;               // 1, or 2 when Doppler scheme 2 needs units of its own (kind 1)
-    int     ncol;                  // 12, or 14 with the two Doppler scheme-2 moments
+    int     ncol;                  // columns of the polarimetric image: 12, or 14 when the two Doppler scheme-2
+                                   // moments ride on the polarimetric units (dop_shared)
     int     dop_shared;            // Doppler moments ride on the polarimetric units (identical PSD)
     LutView lut[CPOL_MAX_CLASSES];
     LutView lut_dop[CPOL_MAX_CLASSES];
@@ -117,7 +119,7 @@ struct cpol_ctx {
     long   stage_launches[CPOL_N_STAGES] = {0};
     int   *valid_host = nullptr;                  // pinned: valid units of each batch
     size_t valid_cap = 0, valid_used = 0;
-    double valid_units = 0;
+    double valid_units = 0, dop_units = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                  \
@@ -148,6 +150,10 @@ void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *
 void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
+void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
+                          const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
+void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
+                            double mu_d, double nu_d, double alpha_d, double beta_d);
 struct SpecParams {
     int    n_gates, n_sub, n_vel;
     float  zfac;                   // wavelength^4 / (pi^5 KW^2) as float32
@@ -166,7 +172,9 @@ struct Dop2In {                    // inputs of the Doppler scheme-2 reduction i
     const double *phi_sc;
     const float2 *lam;
     const double *n0d;
-    int n_cls, ne_max, nt_max, ncol, shared;
+    int n_cls, ne_max, nt_max, shared;
+    int slice_floats;              // floats per (e, t) node of that image
+    int at0[2], at1[2];            // offsets of the two Doppler columns at d = 0 and d = 1023 inside a node
     const float *img[CPOL_MAX_CLASSES];   // table image holding the Doppler columns
     const float *xq[CPOL_MAX_CLASSES];
     int n_t[CPOL_MAX_CLASSES];

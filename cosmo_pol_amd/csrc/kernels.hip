@@ -505,6 +505,38 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
                        ncol, mu, nu, with_dop, zero_pol, mu_d, alpha_d, beta_d);
 }
 
+// Compact image of the Doppler scheme-2 columns for units with a PSD of their own (k_integrate_dop):
+//   img[sl][w = 4 q + k][c][s],  d = 16 q + 4 s + k,  c = 0: D^nu_d,  1: rcs D^mu_d,  2: rcs v(D) D^mu_d
+// i.e. 12 KB per (e, t) node, three 16-byte words per group of four diameters.
+__global__ void k_build_dop_image(const float *__restrict__ raw, const float *__restrict__ d_axis,
+                                  float *__restrict__ img, float *__restrict__ xq, long nslice, double mu_d, double nu_d,
+                                  double alpha_d, double beta_d)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslice * 1024) return;
+    int d = (int)(t % 1024);
+    long sl = t / 1024;
+    float D = d_axis[d];
+    const float *src = raw + (sl * 1024 + d) * CPOL_N_SZ;
+    float rcs = (float)(2 * M_PI) * (((src[0] - src[1]) - src[2]) + src[3]);
+    float xm = (float)pow((double)D, mu_d);
+    float x = (float)pow((double)D, nu_d);
+    int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
+    float *o = img + sl * CPOL_DOP_SLICE + (long)(q * 4 + k) * 12 + s4;
+    o[0] = x;
+    o[4] = rcs * xm;
+    o[8] = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * xm;
+    if (sl == 0) xq[((q * 4 + k) << 2) + s4] = x;
+}
+
+void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
+                            double mu_d, double nu_d, double alpha_d, double beta_d)
+{
+    long total = nslice * 1024;
+    hipLaunchKernelGGL(k_build_dop_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, d_axis, img, xq,
+                       nslice, mu_d, nu_d, alpha_d, beta_d);
+}
+
 // =============================================================================
 // PSD set-up per (gate, sub-beam, class): valid test, nearest lookup-table node,
 // PSD parameters (hydrometeors.py set_psd), bucket histogram; Doppler scheme 1
@@ -779,7 +811,7 @@ template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                  const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
-{
+{   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 4 zero floats read by the lanes of the spare columns
     constexpr int LDS_X = SLICE_FLOATS + 4;
@@ -897,6 +929,83 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
 }
 
 // =============================================================================
+// Doppler scheme 2 for units whose PSD differs from the polarimetric one (2-moment input,
+// doppler_sz.py:57,192,218-220): only the two moments  sum_d N rcs  and  sum_d N v rcs  are needed,
+// two columns where the matrix-core tile has sixteen, so these units run on the vector ALUs:
+// one lane per unit, the node's 12 KB compact image in LDS read as wave-uniform 16-byte words,
+// packed-f32 exponent and accumulate, float64 flush every 128 diameters like k_integrate.
+// Buckets [b_lo, b_hi) of the chunk table.
+// =============================================================================
+__global__ __launch_bounds__(CPOL_CHUNK_UNITS)
+void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
+                     const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
+{
+    __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
+    const int c_lo = chunk_off[b_lo];
+    const unsigned total = (unsigned)(chunk_off[b_hi] - c_lo);
+    const unsigned orig = blockIdx.x;
+    if (orig >= total) return;
+    const unsigned q8 = total / 8, r8 = total % 8, xcd = orig % 8;
+    const int cid = c_lo + (int)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8);
+    int lo = b_lo, hi = b_hi;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (chunk_off[mid] <= cid) lo = mid; else hi = mid;
+    }
+    const int bkt = lo;
+    const int start = offs[bkt] + (cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
+    int cnt = offs[bkt + 1] - start;
+    if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
+    const int it = bkt % ct.nt_max;
+    const int ie = (bkt / ct.nt_max) % ct.ne_max;
+    const int h = bkt / (ct.nt_max * ct.ne_max) - ct.n_cls;
+    const LutView lv = ct.lut_dop[h];
+    const int tid = threadIdx.x;
+    {
+        const float4 *src = (const float4 *)(lv.table + (long)(ie * lv.n_t + it) * CPOL_DOP_SLICE);
+        float4 *dst = (float4 *)lds;
+#pragma unroll
+        for (int i = 0; i < CPOL_DOP_SLICE / 4 / CPOL_CHUNK_UNITS; i++) dst[tid + i * CPOL_CHUNK_UNITS] = src[tid + i * CPOL_CHUNK_UNITS];
+    }
+    __syncthreads();
+    if (tid >= cnt) return;
+    const int slot = sorted[start + tid];
+    const float2 l = lam[slot];
+    const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
+    const float4 *I4 = (const float4 *)lds;
+    double s12 = 0., s13 = 0.;
+    for (int wo = 0; wo < 256; wo += 32) {
+        f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
+#pragma unroll 4
+        for (int w = wo; w < wo + 32; w++) {
+            const float4 x = I4[3 * w], b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
+            const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+            const f32x2 p01 = __builtin_elementwise_fma(nhi, x01, nlo * x01);
+            const f32x2 p23 = __builtin_elementwise_fma(nhi, x23, nlo * x23);
+            const f32x2 n01 = {__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
+            const f32x2 n23 = {__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+            const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
+            a12 = __builtin_elementwise_fma(n01, u01, a12);
+            a13 = __builtin_elementwise_fma(n01, v01, a13);
+            a12 = __builtin_elementwise_fma(n23, u23, a12);
+            a13 = __builtin_elementwise_fma(n23, v23, a13);
+        }
+        s12 += (double)a12.x + (double)a12.y;
+        s13 += (double)a13.x + (double)a13.y;
+    }
+    psd_out[(long)slot * CPOL_N_COL + 12] = (float)s12;
+    psd_out[(long)slot * CPOL_N_COL + 13] = (float)s13;
+}
+
+void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
+                          const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out)
+{
+    if (max_chunks <= 0) return;
+    hipLaunchKernelGGL(k_integrate_dop, dim3((unsigned)max_chunks), dim3(CPOL_CHUNK_UNITS), 0, s, ct, b_lo, b_hi, offs,
+                       chunk_off, sorted, lam, psd_out);
+}
+
+// =============================================================================
 // per-ray reduction: GH-weighted sub-beam sum with the reference's float32 storage
 // (scattering_sz.py:38,105), class sum (:109-110), observables (:164-196), the two
 // range scans (:117-125) as wavefront prefix scans, mask (:144-151), Doppler
@@ -927,15 +1036,13 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
         if (k < 0) continue;
         any = true;
         const int it = k % d2.nt_max, ie = (k / d2.nt_max) % d2.ne_max;
-        const int NC = d2.ncol;
-        const float *img = d2.img[h] + (long)(ie * d2.n_t[h] + it) * 1024 * NC;
+        const float *img = d2.img[h] + (long)(ie * d2.n_t[h] + it) * d2.slice_floats;
         const float2 l = d2.lam[slot];
         const double l2 = (double)l.x + (double)l.y;
         const double e0 = exp2(-l2 * (double)d2.xq[h][0]), e1 = exp2(-l2 * (double)d2.xq[h][1023]);
-        // B'[d][j] at d = 0 and d = 1023 (q = 63, s = 3, k = 3)
-        const long i0 = 0, i1 = (((long)(63 * 4 + 3) * NC) << 2) + 3;
-        double s12 = (double)psd_out[slot * CPOL_N_COL + 12] - 0.5 * (e0 * (double)img[i0 + 12 * 4] + e1 * (double)img[i1 + 12 * 4]);
-        double s13 = (double)psd_out[slot * CPOL_N_COL + 13] - 0.5 * (e0 * (double)img[i0 + 13 * 4] + e1 * (double)img[i1 + 13 * 4]);
+        // the two columns at d = 0 and d = 1023 (offsets into the node's image, set by the host)
+        double s12 = (double)psd_out[slot * CPOL_N_COL + 12] - 0.5 * (e0 * (double)img[d2.at0[0]] + e1 * (double)img[d2.at1[0]]);
+        double s13 = (double)psd_out[slot * CPOL_N_COL + 13] - 0.5 * (e0 * (double)img[d2.at0[1]] + e1 * (double)img[d2.at1[1]]);
         double n0 = d2.n0d[slot];
         double a = n0 * s13, b = n0 * s12;
         vh += (a != a ? 0. : a);

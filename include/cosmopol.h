@@ -100,12 +100,16 @@ int  cpol_synchronize(cpol_ctx *ctx);
  * (no counterpart in the reference, which only has utilities/tictoc.py).  While enabled,
  * every cpol_run_rays* / cpol_observables_from_beams call adds to the totals; read them
  * after cpol_synchronize().  valid_units = number of (gate, sub-beam, class) units that
- * went through the PSD integration, the quantity its arithmetic scales with. */
-#define CPOL_N_STAGES 5
-enum cpol_stage { CPOL_ST_GEOM = 0, CPOL_ST_INTERP, CPOL_ST_PREP_SORT, CPOL_ST_INTEGRATE, CPOL_ST_OBSERVABLES };
+ * went through the PSD integration of the scattering components (stage INTEGRATE), the
+ * quantity its arithmetic scales with; doppler_units = units of the Doppler scheme-2
+ * moments that were integrated separately because their PSD differs (stage INTEGRATE_DOP;
+ * 0 when the moments ride on the polarimetric units). */
+#define CPOL_N_STAGES 6
+enum cpol_stage { CPOL_ST_GEOM = 0, CPOL_ST_INTERP, CPOL_ST_PREP_SORT, CPOL_ST_INTEGRATE, CPOL_ST_OBSERVABLES,
+                  CPOL_ST_INTEGRATE_DOP };
 int cpol_timing_enable(cpol_ctx *ctx, int on);          /* also resets the totals */
 int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_launches[CPOL_N_STAGES],
-                     double *valid_units);
+                     double *valid_units, double *doppler_units);
 /* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
  * workspace the library allocates (default 8 Mi positions, about 3.5 GB). */
 int cpol_set_batch_units(cpol_ctx *ctx, long max_units);
