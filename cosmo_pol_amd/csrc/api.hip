@@ -218,6 +218,7 @@ static void fill_psd(PsdView &v, const cpol_psd &p)
     v.t_var = (p.t_var >= 0 && p.t_var < CPOL_V_COUNT) ? p.t_var : CPOL_V_T;
     v.n0_unit = pow(1000., -(1 + p.mu));
     v.lam_unit = pow(1000., -p.nu);
+    v.log_lam_unit = log(v.lam_unit);
 }
 
 extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,
@@ -244,6 +245,14 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
     L.n_e = lut->n_e; L.n_t = lut->n_t; L.n_d = lut->n_d;
     L.e_min = lut->e_min; L.e_step = lut->e_step; L.t_min = lut->t_min; L.t_step = lut->t_step;
     L.dD = dax[1] - dax[0];
+    // uniform axis (np.linspace, compute_lut_sz.py:104): D_d = D_0 + d * step to within float32 rounding
+    {
+        const double d0 = dax[0], st = ((double)dax[1023] - d0) / 1023.;
+        double dev = 0;
+        for (int d = 0; d < 1024; d++) dev = fmax(dev, fabs((double)dax[d] - (d0 + d * st)) / fabs((double)dax[d]));
+        L.axis_uniform = dev < 2.5e-7;
+        L.axis_step = st;
+    }
     L.psd = *psd;
     L.psd_dop = psd_doppler ? *psd_doppler : *psd;
     L.present = true;
@@ -329,6 +338,9 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         v.e_min = L.e_min; v.e_step = L.e_step; v.t_min = L.t_min; v.t_step = L.t_step; v.dD = L.dD;
         ct.lut_dop[h] = v;
         ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
+        // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
+        // exponential per four diameters
+        ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         fill_psd(ct.psd[h], L.psd);
         fill_psd(ct.dop[h], L.psd_dop);
         if (L.n_e > ct.ne_max) ct.ne_max = L.n_e;

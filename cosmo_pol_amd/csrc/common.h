@@ -23,6 +23,8 @@ struct LutDev {
     float *table_dop = nullptr;    // compact 3-column image of the separate Doppler units (k_integrate_dop)
     float *xq_dop = nullptr;
     float *d_axis = nullptr;       // [n_d]
+    bool   axis_uniform = false;   // diameters equally spaced to float32 rounding
+    double axis_step = 0;
     int    image_ncol = 0;         // what `table` was last built for
     bool   image_dop = false;
     cpol_psd psd, psd_dop;
@@ -42,6 +44,7 @@ struct PsdView {
     double a, b, alpha, beta, mu, nu, lambda_factor, vel_factor, ntot_factor, n0_fixed, x_min, x_max;
     int    q_var, qn_var, t_var;
     double n0_unit, lam_unit;      // 1000^-(1+mu), 1000^-nu (hydrometeors.py:149,151)
+    double log_lam_unit;
 };
 
 struct ClassTable {
@@ -53,6 +56,7 @@ struct ClassTable {
     int     dop_shared;            // Doppler moments ride on the polarimetric units (identical PSD)
     LutView lut[CPOL_MAX_CLASSES];
     LutView lut_dop[CPOL_MAX_CLASSES];
+    float   dop_geo_step[CPOL_MAX_CLASSES];   // 4 x diameter step when the Doppler PSD has nu = 1 on a uniform axis, else 0
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
 };

@@ -562,25 +562,31 @@ __device__ inline double powxy(double x, double y) { return exp(y * log(x)); }
 
 // lambda and N0 of one class at one gate (float64, float32 where the reference's
 // NumPy promotion keeps float32).  Returns false when Q is not usable.
-__device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, double *lam, double *n0)
+__device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, double *lam, double *n0,
+                                  double *loglam = nullptr)
 {
+    double ll;                       // natural log of *lam: later powers of lambda reuse it
     if (p.kind == 0) {
-        *lam = powxy(p.lambda_factor / (double)q, 1. / (4. + p.mu));
+        ll = log(p.lambda_factor / (double)q) * (1. / (4. + p.mu));
+        *lam = exp(ll);
         *n0 = p.n0_fixed;
     } else if (p.kind == 1) {
         // exp through float64 so that subnormal float32 results are kept, as glibc's expf keeps them
         float n0f = 13.5f * (565000.0f * (float)exp((double)(-0.107f * (T - 273.15f)))) / 1000.f;
         float an0 = (float)p.a * n0f;
-        *lam = powxy((double)an0 * p.lambda_factor / (double)q, 1. / (p.b + 1));
+        ll = log((double)an0 * p.lambda_factor / (double)q) * (1. / (p.b + 1));
+        *lam = exp(ll);
         *n0 = (double)n0f;
     } else {
         float xm = q * 1.0f / (qn + 1.1920929e-07f);
         xm = fminf(fmaxf(xm, (float)p.x_min), (float)p.x_max);
-        double l = powxy(p.lambda_factor * (double)xm, -p.nu / p.b);
-        double n = (p.nu / p.ntot_factor) * (double)qn * powxy(l, (p.mu + 1) / p.nu);
+        double l0 = log(p.lambda_factor * (double)xm) * (-p.nu / p.b);
+        double n = (p.nu / p.ntot_factor) * (double)qn * exp(l0 * ((p.mu + 1) / p.nu));
         *n0 = n * p.n0_unit;
-        *lam = l * p.lam_unit;
+        *lam = exp(l0) * p.lam_unit;
+        ll = l0 + p.log_lam_unit;
     }
+    if (loglam) *loglam = ll;
     return true;
 }
 
@@ -679,10 +685,9 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             // a negative mass density (extrapolation below the lowest level) still yields finite
             // 2-moment parameters in the reference (clamped mean mass); the other branches give NaN
             if (q > 0.f || (p.kind == 2 && q < 0.f)) {
-                double l, n0, vi, ni;
+                double l, n0, vi, ni, ll;
                 float Tp = vals[(long)p.t_var * plane + uu];
-                psd_params(p, q, qn, Tp, &l, &n0);
-                double ll = log(l);
+                psd_params(p, q, qn, Tp, &l, &n0, &ll);
                 vi = p.vel_factor * n0 * p.alpha / p.nu * exp(ll * (-(p.beta + p.mu + 1) / p.nu));
                 if (p.kind == 2) ni = (double)qn;
                 else ni = p.ntot_factor * n0 / p.nu * exp(ll * (-(p.mu + 1) / p.nu));
@@ -971,27 +976,53 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     if (tid >= cnt) return;
     const int slot = sorted[start + tid];
     const float2 l = lam[slot];
-    const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
     const float4 *I4 = (const float4 *)lds;
     double s12 = 0., s13 = 0.;
-    for (int wo = 0; wo < 256; wo += 32) {
-        f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
-#pragma unroll 4
-        for (int w = wo; w < wo + 32; w++) {
-            const float4 x = I4[3 * w], b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
-            const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
-            const f32x2 p01 = __builtin_elementwise_fma(nhi, x01, nlo * x01);
-            const f32x2 p23 = __builtin_elementwise_fma(nhi, x23, nlo * x23);
-            const f32x2 n01 = {__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
-            const f32x2 n23 = {__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
-            const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
-            a12 = __builtin_elementwise_fma(n01, u01, a12);
-            a13 = __builtin_elementwise_fma(n01, v01, a13);
-            a12 = __builtin_elementwise_fma(n23, u23, a12);
-            a13 = __builtin_elementwise_fma(n23, v23, a13);
+    const float gstep = ct.dop_geo_step[h];
+    if (gstep > 0.f) {
+        // nu = 1 on a uniform axis: the four diameters of a word are 4 steps apart, so
+        // N = (n, n R, n R^2, n R^3) with R = exp(-lambda 4 step): one exponential per word
+        const float R = __builtin_amdgcn_exp2f(-(l.x * gstep + l.y * gstep));
+        const f32x2 R2 = {R * R, R * R};
+        for (int wo = 0; wo < 256; wo += 32) {
+            f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
+#pragma unroll 8
+            for (int w = wo; w < wo + 32; w++) {
+                const float x0 = lds[12 * w];
+                const float4 b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
+                const float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x0, -l.y * x0));
+                const f32x2 n01 = {n0, n0 * R};
+                const f32x2 n23 = n01 * R2;
+                const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
+                a12 = __builtin_elementwise_fma(n01, u01, a12);
+                a13 = __builtin_elementwise_fma(n01, v01, a13);
+                a12 = __builtin_elementwise_fma(n23, u23, a12);
+                a13 = __builtin_elementwise_fma(n23, v23, a13);
+            }
+            s12 += (double)a12.x + (double)a12.y;
+            s13 += (double)a13.x + (double)a13.y;
         }
-        s12 += (double)a12.x + (double)a12.y;
-        s13 += (double)a13.x + (double)a13.y;
+    } else {
+        const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
+        for (int wo = 0; wo < 256; wo += 32) {
+            f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
+#pragma unroll 4
+            for (int w = wo; w < wo + 32; w++) {
+                const float4 x = I4[3 * w], b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
+                const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+                const f32x2 p01 = __builtin_elementwise_fma(nhi, x01, nlo * x01);
+                const f32x2 p23 = __builtin_elementwise_fma(nhi, x23, nlo * x23);
+                const f32x2 n01 = {__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
+                const f32x2 n23 = {__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+                const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
+                a12 = __builtin_elementwise_fma(n01, u01, a12);
+                a13 = __builtin_elementwise_fma(n01, v01, a13);
+                a12 = __builtin_elementwise_fma(n23, u23, a12);
+                a13 = __builtin_elementwise_fma(n23, v23, a13);
+            }
+            s12 += (double)a12.x + (double)a12.y;
+            s13 += (double)a13.x + (double)a13.y;
+        }
     }
     psd_out[(long)slot * CPOL_N_COL + 12] = (float)s12;
     psd_out[(long)slot * CPOL_N_COL + 13] = (float)s13;
@@ -1010,7 +1041,7 @@ void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, 
 // (scattering_sz.py:38,105), class sum (:109-110), observables (:164-196), the two
 // range scans (:117-125) as wavefront prefix scans, mask (:144-151), Doppler
 // scheme 1/2 averaging (doppler_sz.py:62-87), sensitivity cut (utilities.py:68-105).
-// One wavefront per ray; lanes stride the gates.
+// Two kernels: k_gate_reduce (one thread per gate) and k_ray_scan (one wavefront per ray).
 // =============================================================================
 __device__ inline double wave_scan_incl(double x, int lane)
 {
@@ -1058,82 +1089,106 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
     return (U * d2.phi_sc[2 * rb] + V * d2.phi_sc[2 * rb + 1]) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
 }
 
-__global__ __launch_bounds__(64)
-void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
+// Stage 1, one thread per (ray, gate): sub-beam and class sums, observables without the range scans.
+__global__ __launch_bounds__(256)
+void k_gate_reduce(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
-                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2,
-                   double *__restrict__ spectrum, int n_vel)
+                   long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int G = op.n_gates, B = op.n_sub;
+    if (t >= (long)n_rays * G) return;
+    const int r = (int)(t / G), g = (int)(t % G);
+    const float qnan = __builtin_nanf("");
+    float tot[CPOL_N_SZ];
+#pragma unroll
+    for (int k = 0; k < CPOL_N_SZ; k++) tot[k] = 0.f;
+    double msum = 0, rv = __builtin_nan(""), sw = 0;
+    for (int h = 0; h < op.n_cls; h++) {
+        float acc[CPOL_N_SZ];
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) acc[k] = qnan;
+        for (int b = 0; b < B; b++) {
+            long u = ((long)r * B + b) * G + g;
+            long slot = (long)h * nu + u;
+            if (key[slot] < 0) continue;
+            double c = coef[slot];
+            const float4 *p = (const float4 *)(psd_out + slot * CPOL_N_COL);
+            float4 v0 = p[0], v1 = p[1], v2 = p[2];
+            const float vv[CPOL_N_SZ] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+            for (int k = 0; k < CPOL_N_SZ; k++) {
+                double v = (double)vv[k] * c;
+                double sm = (acc[k] != acc[k] ? 0. : (double)acc[k]) + (v != v ? 0. : v);
+                acc[k] = (float)sm;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) tot[k] += (acc[k] != acc[k]) ? 0.f : acc[k];
+    }
+    for (int b = 0; b < B; b++) {
+        long u = ((long)r * B + b) * G + g;
+        msum += (double)mask[u];
+        if (op.doppler == 1 || op.doppler == 2) {
+            double pw = op.doppler == 2 ? doppler2_radial(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
+            double w = wsub[b];
+            sw += (pw != pw) ? 0. : w;
+            double tt = pw * w;
+            rv = (rv != rv ? 0. : rv) + (tt != tt ? 0. : tt);
+        }
+    }
+    float s[CPOL_N_SZ];
+#pragma unroll
+    for (int k = 0; k < CPOL_N_SZ; k++) s[k] = (tot[k] == 0.f) ? qnan : tot[k];
+    // get_pol_from_sz, float32 in the reference's order
+    float bq = ((s[0] - s[1]) - s[2]) + s[3];
+    float cq = ((s[0] + s[1]) + s[2]) + s[3];
+    float xs_h = op.two_pi * bq, xs_v = op.two_pi * cq;
+    float a1 = s[4] + s[7], a2 = s[6] - s[5];
+    float aq = a1 * a1 + a2 * a2;
+    float delta = atan2f(s[5] - s[6], (-s[4]) - s[7]);
+    const long o = (ray0 + r) * (long)G + g;
+    obs[CPOL_O_ZH * obs_plane + o] = op.zfac * xs_h;
+    obs[CPOL_O_ZV * obs_plane + o] = op.zfac * xs_v;
+    obs[CPOL_O_ZDR * obs_plane + o] = xs_h / xs_v;
+    obs[CPOL_O_KDP * obs_plane + o] = op.kdpfac * (s[10] - s[8]) + delta;        // KDP + delta_hv (scattering_sz.py:117)
+    obs[CPOL_O_DELTA_HV * obs_plane + o] = delta;
+    obs[CPOL_O_RHOHV * obs_plane + o] = sqrtf(aq / (bq * cq));
+    obs[CPOL_O_AH * obs_plane + o] = op.afac * (op.two_wl * s[11]);
+    obs[CPOL_O_AV * obs_plane + o] = op.afac * (op.two_wl * s[9]);
+    if (mask_out) {
+        double m = msum / (double)B;
+        if (m >= 0 && m < 1) m = 0;
+        mask_out[o] = m;
+    }
+    if (rvel_out && (op.doppler == 1 || op.doppler == 2)) rvel_out[o] = rv / sw;
+}
+
+// Stage 2, one wavefront per ray: PHIDP and the attenuation as prefix scans along range, sensitivity cut.
+__global__ __launch_bounds__(64)
+void k_ray_scan(ObsParams op, int n_rays, float *__restrict__ obs, long obs_plane, long ray0,
+                double *__restrict__ rvel_out, double *__restrict__ spectrum, int n_vel)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
-    const int G = op.n_gates, B = op.n_sub;
+    const int G = op.n_gates;
     const float qnan = __builtin_nanf("");
     double carry_phi = 0, carry_h = 0, carry_v = 0;
     for (int g0 = 0; g0 < G; g0 += 64) {
         const int g = g0 + lane;
         const bool act = g < G;
-        float tot[CPOL_N_SZ];
-#pragma unroll
-        for (int k = 0; k < CPOL_N_SZ; k++) tot[k] = 0.f;
-        double msum = 0, rv = __builtin_nan(""), sw = 0;
-        if (act) {
-            for (int h = 0; h < op.n_cls; h++) {
-                float acc[CPOL_N_SZ];
-#pragma unroll
-                for (int k = 0; k < CPOL_N_SZ; k++) acc[k] = qnan;
-                for (int b = 0; b < B; b++) {
-                    long u = ((long)r * B + b) * G + g;
-                    long slot = (long)h * nu + u;
-                    if (key[slot] < 0) continue;
-                    double c = coef[slot];
-                    const float4 *p = (const float4 *)(psd_out + slot * CPOL_N_COL);
-                    float4 v0 = p[0], v1 = p[1], v2 = p[2];
-                    const float vv[CPOL_N_SZ] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-                    for (int k = 0; k < CPOL_N_SZ; k++) {
-                        double v = (double)vv[k] * c;
-                        double s = (acc[k] != acc[k] ? 0. : (double)acc[k]) + (v != v ? 0. : v);
-                        acc[k] = (float)s;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < CPOL_N_SZ; k++) tot[k] += (acc[k] != acc[k]) ? 0.f : acc[k];
-            }
-            for (int b = 0; b < B; b++) {
-                long u = ((long)r * B + b) * G + g;
-                msum += (double)mask[u];
-                if (op.doppler == 1 || op.doppler == 2) {
-                    double pw = op.doppler == 2 ? doppler2_radial(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
-                    double w = wsub[b];
-                    sw += (pw != pw) ? 0. : w;
-                    double t = pw * w;
-                    rv = (rv != rv ? 0. : rv) + (t != t ? 0. : t);
-                }
-            }
-        }
-        float s[CPOL_N_SZ];
-#pragma unroll
-        for (int k = 0; k < CPOL_N_SZ; k++) s[k] = (tot[k] == 0.f) ? qnan : tot[k];
-        // get_pol_from_sz, float32 in the reference's order
-        float bq = ((s[0] - s[1]) - s[2]) + s[3];
-        float cq = ((s[0] + s[1]) + s[2]) + s[3];
-        float xs_h = op.two_pi * bq, xs_v = op.two_pi * cq;
-        float zh = op.zfac * xs_h, zv = op.zfac * xs_v;
-        float zdr = xs_h / xs_v;
-        float kdp = op.kdpfac * (s[10] - s[8]);
-        float ah = op.afac * (op.two_wl * s[11]);
-        float av = op.afac * (op.two_wl * s[9]);
-        float a1 = s[4] + s[7], a2 = s[6] - s[5];
-        float aq = a1 * a1 + a2 * a2;
-        float rhohv = sqrtf(aq / (bq * cq));
-        float delta = atan2f(s[5] - s[6], (-s[4]) - s[7]);
-        float kdpm = kdp + delta;
+        const long o = (ray0 + r) * (long)G + (act ? g : 0);
+        float zh = obs[CPOL_O_ZH * obs_plane + o], zv = obs[CPOL_O_ZV * obs_plane + o];
+        const float kdpm = obs[CPOL_O_KDP * obs_plane + o];
+        const float ah = obs[CPOL_O_AH * obs_plane + o], av = obs[CPOL_O_AV * obs_plane + o];
         // PHIDP = cumsum(nan->0 of 2*KDP_m) * res / 1000
         float two_k = 2.f * kdpm;
         double xphi = (act && two_k == two_k) ? (double)two_k : 0.;
         double sc = wave_scan_incl(xphi, lane) + carry_phi;
         carry_phi = __shfl(sc, 63);
         float phidp = (float)sc * op.res / 1000.f;
+        bool att = false;
+        float zdr = 0.f;
         if (op.att_corr) {
             // cumprod(nan->1 of 10^(-0.1*A*res_km)) = 10^(cumsum of the exponents)
             float eh = (-0.1f * ah) * op.res_km, ev = (-0.1f * av) * op.res_km;
@@ -1143,42 +1198,31 @@ void k_observables(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
             zv *= (float)exp10(sv);
             zh *= (float)exp10(sh);
             zdr = zh / zv;
+            att = true;
         }
-        double rvel = rv / sw;
         bool cut = false;
-        if (op.doppler == 3 && act && rvel_out) rvel = rvel_out[(ray0 + r) * (long)G + g];   // from k_spectrum
         if (op.sens_mode && act) {
             double thr;
             if (op.sens_mode == 1) thr = op.sens0;
             else thr = (op.sens0 - 20 * log10(op.sens1 / 1000.)) + 20 * log10((op.res_d * g) / 1000.);
             float zdb = 10.f * log10f(zh);
-            if ((double)zdb < thr) {
-                zh = qnan; zv = qnan; phidp = qnan; zdr = qnan; rhohv = qnan; kdpm = qnan;
-                rvel = __builtin_nan("");
-                cut = true;
-            }
+            cut = (double)zdb < thr;
         }
         if (act) {
-            long o = (ray0 + r) * (long)G + g;
-            if (obs) {
-                obs[CPOL_O_ZH * obs_plane + o] = zh;
-                obs[CPOL_O_ZDR * obs_plane + o] = zdr;
-                obs[CPOL_O_ZV * obs_plane + o] = zv;
-                obs[CPOL_O_KDP * obs_plane + o] = kdpm;
-                obs[CPOL_O_DELTA_HV * obs_plane + o] = delta;
+            if (cut) {      // utilities.py:96-103: the SIMULATED_VARIABLES of the beam
+                obs[CPOL_O_ZH * obs_plane + o] = qnan; obs[CPOL_O_ZV * obs_plane + o] = qnan;
+                obs[CPOL_O_ZDR * obs_plane + o] = qnan; obs[CPOL_O_KDP * obs_plane + o] = qnan;
+                obs[CPOL_O_RHOHV * obs_plane + o] = qnan; obs[CPOL_O_PHIDP * obs_plane + o] = qnan;
+                if (rvel_out && op.doppler) rvel_out[o] = __builtin_nan("");
+                if (spectrum)
+                    for (int i = 0; i < n_vel; i++) spectrum[o * n_vel + i] = __builtin_nan("");
+            } else {
                 obs[CPOL_O_PHIDP * obs_plane + o] = phidp;
-                obs[CPOL_O_RHOHV * obs_plane + o] = rhohv;
-                obs[CPOL_O_AH * obs_plane + o] = ah;
-                obs[CPOL_O_AV * obs_plane + o] = av;
+                if (att) {
+                    obs[CPOL_O_ZH * obs_plane + o] = zh; obs[CPOL_O_ZV * obs_plane + o] = zv;
+                    obs[CPOL_O_ZDR * obs_plane + o] = zdr;
+                }
             }
-            if (mask_out) {
-                double m = msum / (double)B;
-                if (m >= 0 && m < 1) m = 0;
-                mask_out[o] = m;
-            }
-            if (rvel_out && op.doppler) rvel_out[o] = rvel;
-            if (cut && spectrum)
-                for (int i = 0; i < n_vel; i++) spectrum[o * n_vel + i] = __builtin_nan("");
         }
     }
 }
@@ -1188,8 +1232,11 @@ void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel)
 {
-    hipLaunchKernelGGL(k_observables, dim3(n_rays), dim3(64), 0, s, op, n_rays, nu, key, coef, psd_out, mask,
-                       weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2, spectrum, n_vel);
+    const long n = (long)n_rays * op.n_gates;
+    hipLaunchKernelGGL(k_gate_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, n_rays, nu, key, coef,
+                       psd_out, mask, weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
+    hipLaunchKernelGGL(k_ray_scan, dim3(n_rays), dim3(64), 0, s, op, n_rays, obs, obs_plane, ray0, rvel_out, spectrum,
+                       n_vel);
 }
 
 // geometry of the central sub-beam (scattering_sz.py:154-157)
