@@ -252,6 +252,7 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
         for (int d = 0; d < 1024; d++) dev = fmax(dev, fabs((double)dax[d] - (d0 + d * st)) / fabs((double)dax[d]));
         L.axis_uniform = dev < 2.5e-7;
         L.axis_step = st;
+        L.d0 = dax[0];
     }
     L.psd = *psd;
     L.psd_dop = psd_doppler ? *psd_doppler : *psd;
@@ -340,6 +341,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
         // exponential per four diameters
+        ct.dop_x0[h] = (double)(float)pow((double)L.d0, L.psd_dop.nu);
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         fill_psd(ct.psd[h], L.psd);
         fill_psd(ct.dop[h], L.psd_dop);
@@ -408,7 +410,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
                 (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
                 (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, hist, offs, cursor, chunk_off);
-    launch_scatter(ctx->stream, nu, n_planes, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, cursor,
+    launch_scatter(ctx->stream, nu, n_planes, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
                    (int *)ctx->b_sorted.p);
     }
     if (ctx->timing) {

@@ -25,6 +25,7 @@ struct LutDev {
     float *d_axis = nullptr;       // [n_d]
     bool   axis_uniform = false;   // diameters equally spaced to float32 rounding
     double axis_step = 0;
+    float  d0 = 0;                 // first diameter
     int    image_ncol = 0;         // what `table` was last built for
     bool   image_dop = false;
     cpol_psd psd, psd_dop;
@@ -56,6 +57,7 @@ struct ClassTable {
     int     dop_shared;            // Doppler moments ride on the polarimetric units (identical PSD)
     LutView lut[CPOL_MAX_CLASSES];
     LutView lut_dop[CPOL_MAX_CLASSES];
+    double  dop_x0[CPOL_MAX_CLASSES];         // D_0^nu of the Doppler PSD as float32 (separate Doppler units)
     float   dop_geo_step[CPOL_MAX_CLASSES];   // 4 x diameter step when the Doppler PSD has nu = 1 on a uniform axis, else 0
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
@@ -151,7 +153,8 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
                         double beta_d);
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off);
-void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *cursor, int *sorted);
+void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *offs,
+                    const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,

@@ -506,8 +506,10 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 }
 
 // Compact image of the Doppler scheme-2 columns for units with a PSD of their own (k_integrate_dop):
-//   img[sl][w = 4 q + k][c][s],  d = 16 q + 4 s + k,  c = 0: D^nu_d,  1: rcs D^mu_d,  2: rcs v(D) D^mu_d
-// i.e. 12 KB per (e, t) node, three 16-byte words per group of four diameters.
+//   img[sl][w = 4 q + k][c][s],  d = 16 q + 4 s + k,  c = 0: D^nu_d - D_0^nu_d,  1: rcs D^mu_d,  2: rcs v(D) D^mu_d
+// i.e. 12 KB per (e, t) node, three 16-byte words per group of four diameters.  The exponent is taken
+// relative to the first diameter (k_prep folds exp(-lambda D_0^nu) into the unit's N0), so that the float32
+// sums keep their leading terms however large lambda is; the reference integrates in float64.
 __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__restrict__ d_axis,
                                   float *__restrict__ img, float *__restrict__ xq, long nslice, double mu_d, double nu_d,
                                   double alpha_d, double beta_d)
@@ -521,9 +523,10 @@ __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__
     float rcs = (float)(2 * M_PI) * (((src[0] - src[1]) - src[2]) + src[3]);
     float xm = (float)pow((double)D, mu_d);
     float x = (float)pow((double)D, nu_d);
+    float x0 = (float)pow((double)d_axis[0], nu_d);
     int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
     float *o = img + sl * CPOL_DOP_SLICE + (long)(q * 4 + k) * 12 + s4;
-    o[0] = x;
+    o[0] = (float)((double)x - (double)x0);
     o[4] = rcs * xm;
     o[8] = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * xm;
     if (sl == 0) xq[((q * 4 + k) << 2) + s4] = x;
@@ -665,7 +668,7 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
                 double l2 = l * 1.4426950408889634;
                 float hi = (float)l2;
                 lam[dslot] = make_float2(hi, (float)(l2 - (double)hi));
-                n0d[dslot] = n0;
+                n0d[dslot] = n0 * exp2(-l2 * ct.dop_x0[h]);      // k_integrate_dop works relative to the first diameter
             }
             if (live) key[dslot] = kd;
             wave_run(kd, lane, &hl, &len);
@@ -731,68 +734,80 @@ void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, cons
                        elev, mask, weight_per_sub, n_sub, phi_sc, doppler, key, rank, lam, coef, n0d, hist, vr);
 }
 
-// Exclusive scan of the sharded bucket histogram (nb <= 8192 buckets x CPOL_SORT_SHARDS
-// counters) -> bucket offsets, per-shard scatter cursors and the chunk table of the
-// integrate kernel.  One workgroup.
-__global__ void k_scan(int nb, const int *__restrict__ hist, int *__restrict__ offs, int *__restrict__ cursor,
-                       int *__restrict__ chunk_off)
+// Offsets from the sharded bucket histogram (nb <= 16384 buckets x CPOL_SORT_SHARDS counters):
+// k_scan_shards (one thread per bucket) turns a bucket's counters into shard cursors relative to the
+// bucket start and leaves the bucket's unit and chunk counts in offs / chunk_off; k_scan_buckets (one
+// workgroup) scans those in place into bucket offsets and the chunk table of the integrate kernels.
+__global__ void k_scan_shards(int nb, const int *__restrict__ hist, int *__restrict__ offs, int *__restrict__ cursor,
+                              int *__restrict__ chunk_off)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    const int4 *h4 = (const int4 *)(hist + j * CPOL_SORT_SHARDS);
+    int4 *c4 = (int4 *)(cursor + j * CPOL_SORT_SHARDS);
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < CPOL_SORT_SHARDS / 4; i++) {
+        int4 h = h4[i], c;
+        c.x = v; v += h.x; c.y = v; v += h.y; c.z = v; v += h.z; c.w = v; v += h.w;
+        c4[i] = c;
+    }
+    offs[j] = v;
+    chunk_off[j] = (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
+}
+
+__global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__ chunk_off)
 {
     __shared__ int s_a[1024], s_b[1024];
-    int t = threadIdx.x;
-    int per = (nb + 1023) / 1024;
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;          // <= 16
+    int va[16], vb[16];
     int a = 0, c = 0;
     for (int i = 0; i < per; i++) {
         int j = t * per + i;
-        int v = 0;
-        if (j < nb)
-            for (int sh = 0; sh < CPOL_SORT_SHARDS; sh++) v += hist[j * CPOL_SORT_SHARDS + sh];
-        a += v;
-        c += (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
+        va[i] = j < nb ? offs[j] : 0;
+        vb[i] = j < nb ? chunk_off[j] : 0;
+        a += va[i]; c += vb[i];
     }
     s_a[t] = a; s_b[t] = c;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        int va = t >= d ? s_a[t - d] : 0, vb = t >= d ? s_b[t - d] : 0;
+        int xa = t >= d ? s_a[t - d] : 0, xb = t >= d ? s_b[t - d] : 0;
         __syncthreads();
-        s_a[t] += va; s_b[t] += vb;
+        s_a[t] += xa; s_b[t] += xb;
         __syncthreads();
     }
     int ea = s_a[t] - a, eb = s_b[t] - c;
     for (int i = 0; i < per; i++) {
         int j = t * per + i;
-        if (j < nb) {
-            offs[j] = ea; chunk_off[j] = eb;
-            int v = 0;
-            for (int sh = 0; sh < CPOL_SORT_SHARDS; sh++) {
-                cursor[j * CPOL_SORT_SHARDS + sh] = ea + v;
-                v += hist[j * CPOL_SORT_SHARDS + sh];
-            }
-            ea += v;
-            eb += (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
-        }
+        if (j < nb) { offs[j] = ea; chunk_off[j] = eb; }
+        ea += va[i]; eb += vb[i];
     }
     if (t == 1023) { offs[nb] = s_a[1023]; chunk_off[nb] = s_b[1023]; }
 }
 
 void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nb, hist, offs, cursor, chunk_off);
+    hipLaunchKernelGGL(k_scan_shards, dim3((nb + 255) / 256), dim3(256), 0, s, nb, hist, offs, cursor, chunk_off);
+    hipLaunchKernelGGL(k_scan_buckets, dim3(1), dim3(1024), 0, s, nb, offs, chunk_off);
 }
 
-// Final position of every valid unit = start of its (bucket, shard) range + the rank k_prep drew.
+// Final position of every valid unit = bucket start + start of its shard inside the bucket + the rank
+// k_prep drew.
 __global__ void k_scatter(long nu, const int *__restrict__ key, const int *__restrict__ rank,
-                          const int *__restrict__ cursor, int *__restrict__ sorted)
+                          const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
     long slot = (long)blockIdx.y * nu + u;
     int k = key[slot];
-    if (k >= 0) sorted[cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
+    if (k >= 0) sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
 }
 
-void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *cursor, int *sorted)
+void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *offs,
+                    const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, key, rank, cursor, sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, key, rank, offs, cursor, sorted);
 }
 
 // =============================================================================
@@ -1024,6 +1039,15 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
             s13 += (double)a13.x + (double)a13.y;
         }
     }
+    // unit-spacing trapezoid rule (doppler_sz.py:219-220): the sum minus half of the two end terms
+    {
+        const int wl = 12 * 255 + 3;                 // d = 1023 is the last element of the last word
+        const float x0 = lds[0], xl = lds[wl];
+        const float na = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x0, -l.y * x0));
+        const float nz = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, xl, -l.y * xl));
+        s12 -= 0.5 * ((double)na * (double)lds[4] + (double)nz * (double)lds[wl + 4]);
+        s13 -= 0.5 * ((double)na * (double)lds[8] + (double)nz * (double)lds[wl + 8]);
+    }
     psd_out[(long)slot * CPOL_N_COL + 12] = (float)s12;
     psd_out[(long)slot * CPOL_N_COL + 13] = (float)s13;
 }
@@ -1066,14 +1090,17 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
         int k = key[slot];
         if (k < 0) continue;
         any = true;
-        const int it = k % d2.nt_max, ie = (k / d2.nt_max) % d2.ne_max;
-        const float *img = d2.img[h] + (long)(ie * d2.n_t[h] + it) * d2.slice_floats;
-        const float2 l = d2.lam[slot];
-        const double l2 = (double)l.x + (double)l.y;
-        const double e0 = exp2(-l2 * (double)d2.xq[h][0]), e1 = exp2(-l2 * (double)d2.xq[h][1023]);
-        // the two columns at d = 0 and d = 1023 (offsets into the node's image, set by the host)
-        double s12 = (double)psd_out[slot * CPOL_N_COL + 12] - 0.5 * (e0 * (double)img[d2.at0[0]] + e1 * (double)img[d2.at1[0]]);
-        double s13 = (double)psd_out[slot * CPOL_N_COL + 13] - 0.5 * (e0 * (double)img[d2.at0[1]] + e1 * (double)img[d2.at1[1]]);
+        double s12 = (double)psd_out[slot * CPOL_N_COL + 12], s13 = (double)psd_out[slot * CPOL_N_COL + 13];
+        if (d2.shared) {
+            // the MFMA columns hold plain sums: take half of the end terms off (unit-spacing trapezoid rule)
+            const int it = k % d2.nt_max, ie = (k / d2.nt_max) % d2.ne_max;
+            const float *img = d2.img[h] + (long)(ie * d2.n_t[h] + it) * d2.slice_floats;
+            const float2 l = d2.lam[slot];
+            const double l2 = (double)l.x + (double)l.y;
+            const double e0 = exp2(-l2 * (double)d2.xq[h][0]), e1 = exp2(-l2 * (double)d2.xq[h][1023]);
+            s12 -= 0.5 * (e0 * (double)img[d2.at0[0]] + e1 * (double)img[d2.at1[0]]);
+            s13 -= 0.5 * (e0 * (double)img[d2.at0[1]] + e1 * (double)img[d2.at1[1]]);
+        }
         double n0 = d2.n0d[slot];
         double a = n0 * s13, b = n0 * s12;
         vh += (a != a ? 0. : a);
