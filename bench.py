@@ -40,7 +40,10 @@ FLOP_PER_UNIT_DOP2 = 6 * N_D      # Doppler scheme 2: two more columns (N rcs, N
 
 def workload_config(small=False, doppler=2):
     from cosmo_pol_amd import cfg
-    conf = {'radar': {'coords': [46.04079, 8.83321, 1604], 'type': 'ground', 'frequency': 5.6,
+    # Monte Lema's position; the altitude is 80 m above the synthetic terrain at that grid cell (a radar below
+    # the terrain would see NaN air density at its first gate, which the reference turns into NaN RVEL for
+    # the whole ray, doppler_sz.py:231)
+    conf = {'radar': {'coords': [46.04079, 8.83321, 2050], 'type': 'ground', 'frequency': 5.6,
                       'range': 250000, 'radial_resolution': 500, 'PRI': 700, 'FFT_length': 128,
                       'sensitivity': [-15, 10000], '3dB_beamwidth': 1.},
             'integration': {'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.},
@@ -203,6 +206,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     finite = float(torch.isfinite(obs_t[0]).float().mean().item())
+    finite_rvel = float(torch.isfinite(rvel_t).float().mean().item()) if args.doppler else None
 
     if rank == 0:
         gates_per_step = (len(azs) * G) * (world if args.scaling == 'weak' else 1)
@@ -234,7 +238,7 @@ def main():
             'stage_ms_per_step': {k: v / args.steps for k, v in tim['ms'].items()},
             'valid_units_per_step': tim['valid_units'] / args.steps,
             'doppler_units_per_step': tim['doppler_units'] / args.steps,
-            'finite_zh_fraction': finite,
+            'finite_zh_fraction': finite, 'finite_rvel_fraction': finite_rvel,
             'cpu_baseline': cpu,
         }
         print(json.dumps(line))

@@ -1,0 +1,121 @@
+"""Full-size run of the headline workload (20 elevations x 360 azimuths x 500 gates on the 80 x 774 x 1158
+grid, 2-moment, 3 x 3 sub-beams) checked through properties that need no CPU run of the whole volume, plus a
+handful of its rays against the oracle.  Everything goes through the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench                                                   # noqa: E402  workload definition only
+from cosmo_pol_amd import _lib, engine, synthetic as syn      # noqa: E402
+from cosmo_pol_amd.lut import Lookup_table                    # noqa: E402
+from oracle import cosmo_oracle as O                           # noqa: E402
+from tests import util                                         # noqa: E402
+from tests.test_gpu_parity import check_obs                    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+OBS = _lib.OBS_NAMES
+
+
+@pytest.fixture(scope='module')
+def volume():
+    import copy
+    conf = copy.deepcopy(bench.workload_config(False, doppler=2))
+    azs, elv = bench.volume_rays(False)
+    model = syn.synthetic_model(80, 774, 1158, scheme=2, seed=20161111, res=(0.01, 0.01))
+    tabs = {h: syn.synthetic_lut(h, 5.6) for h in syn.hydrom_types(2)}
+    eng = engine.Engine(conf, device=0)
+    eng.upload_luts({h: Lookup_table.from_arrays(*t) for h, t in tabs.items()})
+    eng.upload_model(model['fields'], model['zlev'], model['proj_info'], model['resolution'])
+    eng.set_gauss_hermite()
+    out = eng.ctx.run_rays(azs, elv)
+    return dict(conf=conf, azs=azs, elv=elv, model=model, tabs=tabs, eng=eng, out=out)
+
+
+def test_volume_sane(volume):
+    out = volume['out']
+    assert out['obs'].shape == (9, 7200, 500)
+    assert (out['ray_status'] == 0).all()
+    m = np.unique(out['mask'])          # mean of the sub-beam masks, [0, 1) -> 0 (scattering_sz.py:144-151)
+    assert m.max() <= 1.0 and m.min() >= -1.0 and not ((m > 0) & (m < 1)).any()
+    zh = out['obs'][OBS.index('ZH')]
+    assert 0.3 < np.isfinite(zh).mean() < 0.95
+    # gates the model does not cover carry no observables
+    assert np.isnan(zh[out['mask'] == 1]).all()
+    assert np.isfinite(out['rvel']).mean() > 0.3
+
+
+def test_scan_identities(volume):
+    """PHIDP is the range cumsum of 2 KDP and ZDR = ZH / ZV everywhere (scattering_sz.py:117-125), recomputed
+    on the host from the other output fields of the whole volume."""
+    out, conf = volume['out'], volume['conf']
+    o = {n: out['obs'][i] for i, n in enumerate(OBS)}
+    res_km = conf['radar']['radial_resolution'] / 1000.
+    two_k = np.nan_to_num(2. * o['KDP'].astype(np.float64))
+    want = np.cumsum(two_k, axis=1) * res_km
+    scale = np.cumsum(np.abs(two_k), axis=1) * res_km
+    assert np.all(np.abs(o['PHIDP'] - want) <= 2e-6 * scale + 1e-30)
+    ok = np.isfinite(o['ZH'])
+    np.testing.assert_allclose(o['ZDR'][ok], (o['ZH'] / o['ZV'])[ok], rtol=3e-7)
+
+
+def test_attenuation_is_cumprod_of_AH(volume):
+    """ZH with correction = ZH without x cumprod(10^(-0.1 AH res_km)), inclusive (scattering_sz.py:120-125)."""
+    eng, conf, out = volume['eng'], volume['conf'], volume['out']
+    import copy
+    conf0 = copy.deepcopy(conf)
+    conf0['attenuation']['correction'] = 0
+    eng.configure(conf0)
+    sel = np.arange(0, 7200, 7)
+    out0 = eng.ctx.run_rays(volume['azs'][sel], volume['elv'][sel])
+    eng.configure(conf)
+    res_km = conf['radar']['radial_resolution'] / 1000.
+    for zn, an in (('ZH', 'AH'), ('ZV', 'AV')):
+        z1 = out['obs'][OBS.index(zn)][sel].astype(np.float64)
+        z0 = out0['obs'][OBS.index(zn)].astype(np.float64)
+        a = out0['obs'][OBS.index(an)].astype(np.float64)
+        np.testing.assert_array_equal(a, out['obs'][OBS.index(an)][sel])
+        fac = 10 ** np.cumsum(np.nan_to_num(-0.1 * a * res_km), axis=1)
+        ok = np.isfinite(z0)
+        np.testing.assert_array_equal(np.isfinite(z1), ok)
+        np.testing.assert_allclose(z1[ok], (z0 * fac)[ok], rtol=2e-6)
+
+
+def test_batching_and_ray_order_do_not_matter(volume):
+    """Every output of a ray is bit-identical whatever batch it is processed in and whatever its position in
+    the call (the bucket sort only decides which workgroup integrates a unit, never how)."""
+    eng, out = volume['eng'], volume['out']
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(7200)[:2500]
+    eng.ctx.set_batch_units(3 * 1000 * 1000)
+    try:
+        out2 = eng.ctx.run_rays(volume['azs'][perm], volume['elv'][perm])
+    finally:
+        eng.ctx.set_batch_units(8 << 20)
+    for k in ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height'):
+        a = out[k][:, perm] if k == 'obs' else out[k][perm]
+        b = out2[k]
+        assert a.tobytes() == b.tobytes(), k
+
+
+def test_sampled_rays_vs_oracle(volume):
+    """Six rays of the volume through the CPU restatement of the whole path."""
+    conf, out, model = volume['conf'], volume['out'], volume['model']
+    attrs = {'z-levels': model['zlev'], 'proj_info': model['proj_info'], 'resolution': model['resolution']}
+    dic = {n: O.ModelVar(a, attrs) for n, a in model['fields'].items()}
+    luts = {h: O.Lut(*t) for h, t in volume['tabs'].items()}
+    for r in (3, 1111, 2345, 3600 + 17, 5000, 7199):
+        with np.errstate(all='ignore'):
+            beams = O.get_profiles_GH(dic, volume['azs'][r], volume['elv'][r], conf)
+            want_v = O.get_doppler_velocity(beams, luts, conf)
+            want = O.get_radar_observables(beams, luts, conf)
+            want.values.update(want_v.values)
+        check_obs(out['obs'][:, r], want.values, 'ray %d' % r)
+        np.testing.assert_array_equal(out['mask'][r], want.mask)
+        util.assert_close(out['rvel'][r], want.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL %d' % r)
+        np.testing.assert_array_equal(out['dist'][r], want.dist_profile)
+        np.testing.assert_array_equal(out['height'][r], want.heights_profile)

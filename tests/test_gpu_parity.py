@@ -95,34 +95,35 @@ def test_doppler_vs_golden(ds):
     eng = make_engine(conf)
     beams = util.beams_from_golden(g)
     obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
-    util.assert_close(rvel, g['out_RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
-    np.testing.assert_array_equal(mask, g['out_mask'])
+    n_moved = 0
     if ds == 3:
         np.testing.assert_allclose(eng.varray, g['varray'], rtol=0, atol=0)
-        check_spectrum(eng.ctx.last_spectrum, g['out_DSPECTRUM'])
+        n_moved = check_spectrum(eng.ctx.last_spectrum, g['out_DSPECTRUM'])
+    util.assert_close(rvel, g['out_RVEL'], rtol=1e-5, atol=0.02 if n_moved else 1e-6, name='RVEL')
+    np.testing.assert_array_equal(mask, g['out_mask'])
 
 
-def check_spectrum(got, want, n_edge=0):
-    """Every bin is a float32 sum of float64 terms (doppler_c.c:24-26) scaled and GH-weighted: same zero pattern,
-    and values to a few float32 ulps of the gate's largest bin.
+def check_spectrum(got, want):
+    """Doppler spectrum [gates, velocity bins] against the reference / oracle.  Returns the number of bins where
+    a table term sits in the neighbouring bin (see below); RVEL of such gates is compared to 0.02 m/s.
 
-    n_edge > 0 (low elevations): the fall speed of a bin edge is W + wind/tan(el) - v/sin(el) evaluated with
-    float32 sin and tan (doppler_sz.py:341), a few m/s left over from hundreds, so one ulp of sin or tan moves an
-    edge by 1e-5 relative and with it one table term from one bin to the next.  NumPy's float32 sin / tan are
-    not correctly rounded (5 % / 25 % of arguments differ from the rounded exact value on AVX512), so the
-    reference's own output changes with the CPU it runs on; up to n_edge bins per gate may then differ by one
-    term (a few percent of the gate's peak)."""
+    Every bin is a float32 sum of float64 terms (doppler_c.c:24-26), scaled and GH-weighted.  Which terms a bin
+    takes is decided by its edges' fall speed W + wind/tan(el) - v/sin(el) (doppler_sz.py:341), evaluated with
+    float32 sin and tan: a few m/s left over from tens or hundreds, so the last bit of sin / tan moves all edges
+    of a gate by about 1e-6 relative, and with ~1000 diameters per class about one edge per gate and sub-beam
+    then falls on the other side of a table node.  NumPy's float32 sin / tan are not correctly rounded (5 % /
+    25 % of arguments differ from the rounded exact value with its AVX512 kernels, which also differ from
+    libm's), so the reference's own spectrum changes in this way with the CPU it runs on.  The kernel uses the
+    correctly rounded values.  Asserted: identical zero pattern; at least 99 % of the bins to 2e-6 relative +
+    1e-6 of the gate's peak; the others within 5 % of the gate's peak; per-gate power over the former to 3e-6."""
     assert got.shape == want.shape
     np.testing.assert_array_equal(got == 0, want == 0)
     peak = np.abs(want).max(axis=1, keepdims=True)
     bad = np.abs(got - want) > 2e-6 * np.abs(want) + 1e-6 * peak
-    if n_edge:
-        assert bad.sum(axis=1).max() <= n_edge and bad.mean() < 0.01
-        assert np.all(np.abs(got - want)[bad] <= 0.05 * np.broadcast_to(peak, want.shape)[bad])
-        return int(bad.sum())
-    assert not bad.any(), "%d bins differ, first %s: got %r want %r (gate peak %r)" % (
-        bad.sum(), np.argwhere(bad)[0], got[bad][0], want[bad][0], peak[np.argwhere(bad)[0][0], 0])
-    return 0
+    assert bad.mean() < 0.01, "%d of %d bins differ" % (bad.sum(), bad.size)
+    assert np.all(np.abs(got - want)[bad] <= 0.05 * np.broadcast_to(peak, want.shape)[bad])
+    np.testing.assert_allclose(np.where(bad, 0., got).sum(axis=1), np.where(bad, 0., want).sum(axis=1), rtol=3e-6)
+    return int(bad.sum())
 
 
 @pytest.mark.parametrize('n_gates,n_sub', [(40, 1), (24, 9)])
@@ -138,8 +139,8 @@ def test_doppler_spectrum_vs_oracle(n_gates, n_sub):
         want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf, get_refl=O.get_refl_c)
         want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
     check_obs(obs, want.values, 'oracle', res_km=0.25)
-    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
-    check_spectrum(eng.ctx.last_spectrum, want_v.values['DSPECTRUM'])
+    n_moved = check_spectrum(eng.ctx.last_spectrum, want_v.values['DSPECTRUM'])
+    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=0.02 if n_moved else 1e-6, name='RVEL')
 
 
 def test_doppler_scheme3_needs_one_moment():
@@ -432,7 +433,88 @@ def test_radar_operator_rhi_doppler_spectrum():
         got = spec[i].filled(np.nan)
         np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
         ok = ~np.isnan(want).any(axis=1)
-        n_moved = check_spectrum(got[ok], want[ok], n_edge=2 if el < 8 else 0)
+        n_moved = check_spectrum(got[ok], want[ok])
         rv = radar.get_field(0, 'RVEL')[i].filled(np.nan)
-        util.assert_close(rv, b.values['RVEL'], rtol=1e-5, atol=0.05 if n_moved else 1e-6, name='RVEL')
+        util.assert_close(rv, b.values['RVEL'], rtol=1e-5, atol=0.02 if n_moved else 1e-6, name='RVEL')
     assert cut > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# the five reference configurations, shaped like their option files, on a small model
+# ---------------------------------------------------------------------------------------------
+REFERENCE_CONFIGS = {
+    # option_files/test_strat.yml:1-25: C-band PPI, 50 km at 75 m (667 gates), 1-moment, one sub-beam
+    'test_strat': dict(kind='ppi', mp=1, freq=5.6, rng=50000., res=75., nh=1, nv=1, dop=1, bw=1.45,
+                       rays=[(1.0, 30.), (1.0, 211.)]),
+    # option_files/MXPOL_RHI.yml: RHI, 50 km at 75 m, 1-moment, 3 x 3 Gauss-Hermite
+    'MXPOL_RHI': dict(kind='rhi', mp=1, freq=5.6, rng=50000., res=75., nh=3, nv=3, dop=1, bw=1.45,
+                      rays=[(2.0, 47.), (35.0, 47.)]),
+    # option_files/MXPOL_RHI_new_scheme.yml:5-6 (500 m -> 100 gates), 2-moment, nh = 3, nv = 9 (cfg.py:39-40)
+    'MXPOL_RHI_new_scheme': dict(kind='rhi', mp=2, freq=5.6, rng=50000., res=500., nh=3, nv=9, dop=1, bw=1.45,
+                                 rays=[(5.0, 140.), (60.0, 140.)]),
+    # option_files/CH_PPI_lema.yml: 150 km at 500 m (300 gates), 9 x 9 sub-beams, 2-moment input
+    'CH_PPI_lema': dict(kind='ppi', mp=2, freq=5.6, rng=150000., res=500., nh=9, nv=9, dop=2, bw=1.0,
+                        rays=[(1.6, 300.)]),
+    # option_files/MXPOL_RHI_PAYERNE_DOPPLER.yml:4-23: X band, 11 km at 75 m (147 gates), FFT 256, full spectrum
+    'MXPOL_RHI_PAYERNE_DOPPLER': dict(kind='rhi', mp=1, freq=9.41, rng=11000., res=75., nh=3, nv=3, dop=3, bw=1.45,
+                                      rays=[(10.0, 90.), (45.0, 90.)]),
+}
+
+
+@pytest.mark.parametrize('name', sorted(REFERENCE_CONFIGS))
+def test_reference_configuration(name):
+    """RadarOperator.get_PPI / get_RHI under each of the reference's option files (settings restated), a few
+    rays each, every field against the CPU restatement of radar_operator.py:241-244."""
+    from cosmo_pol_amd import RadarOperator, cfg as pcfg, model as pmodel, runtime
+    from cosmo_pol_amd.constants import constants
+    c = REFERENCE_CONFIGS[name]
+    conf = O.make_config(microphysics={'scheme': c['mp']}, doppler={'scheme': c['dop']},
+                         radar={'coords': [46.0, 8.5, 1500.], 'radial_resolution': c['res'], 'range': c['rng'],
+                                'frequency': c['freq'], '3dB_beamwidth': c['bw'], 'PRI': 700, 'FFT_length': 256,
+                                'sensitivity': [-30, 10000]},
+                         integration={'scheme': 1, 'nh_GH': c['nh'], 'nv_GH': c['nv'], 'weight_threshold': 1.})
+    runtime.reset()
+    pcfg.set_config(conf)
+    constants.update()
+    m = syn.synthetic_model(nz=20, ny=90, nx=90, scheme=c['mp'], seed=11, llc=(-2.25, -2.25), res=(0.05, 0.05),
+                            pole=(-44.0, 8.5), ztop=15000.)
+    dic = pmodel.variables_from_arrays(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    tabs = util.synthetic_lut_arrays(c['mp'], c['freq'])
+    op = RadarOperator(conf)
+    op.load_model_file(dic)
+    op.set_lut(c['mp'], {h: Lookup_table.from_arrays(*t) for h, t in tabs.items()})
+    olut = util.oracle_luts(c['mp'], c['freq'])
+    for el, az in c['rays']:
+        radar = op.get_PPI([el], azimuths=[az]) if c['kind'] == 'ppi' else op.get_RHI(az, elevations=[el])
+        n_gates = int(round(c['rng'] / c['res']))
+        assert radar.fields['ZH']['data'].shape == (1, n_gates)
+        with np.errstate(all='ignore'):
+            beams = O.get_profiles_GH(oracle_model_vars(m), az, el, conf)
+            assert len(beams) == c['nh'] * c['nv']
+            get_refl = O.get_refl_c if c['dop'] == 3 else O.get_refl_np
+            want = O.get_radar_observables(beams, olut, conf)
+            want.values.update(O.get_doppler_velocity(beams, olut, conf, get_refl=get_refl).values)
+            O.cut_at_sensitivity([want], conf)
+        got = {}
+        for n in OBS:
+            if n in radar.fields:
+                a = radar.fields[n]['data'][0].filled(np.nan).astype(np.float64)
+                got[n] = 10 ** (0.1 * a) if n in ('ZH', 'ZV', 'ZDR') else a          # back from dB
+        for n in ('ZH', 'ZV', 'ZDR'):
+            w = want.values[n]
+            ok = ~np.isnan(w)
+            np.testing.assert_array_equal(np.isnan(got[n]), ~ok, err_msg=n)
+            assert np.abs(10 * np.log10(got[n][ok] / w[ok])).max() < 0.01, n
+        assert np.nanmax(np.abs(got['KDP'] - want.values['KDP']), initial=0.) < 1e-3
+        for n in ('KDP', 'RHOHV', 'AH', 'AV', 'DELTA_HV'):
+            util.assert_close(got[n], want.values[n], rtol=1e-5,
+                              atol=1e-5 * np.nanmax(np.abs(want.values['KDP']), initial=0.) if n != 'RHOHV' else 0., name=n)
+        n_moved = 0
+        if c['dop'] == 3:
+            sp = radar.fields['DSPECTRUM']['data'][0].filled(np.nan)
+            ws = want.values['DSPECTRUM']
+            np.testing.assert_array_equal(np.isnan(sp), np.isnan(ws))
+            okr = ~np.isnan(ws).any(axis=1)
+            n_moved = check_spectrum(sp[okr], ws[okr])
+        rv = radar.fields['RVEL']['data'][0].filled(np.nan)
+        util.assert_close(rv, want.values['RVEL'], rtol=1e-5, atol=0.02 if n_moved else 1e-6, name='RVEL')
