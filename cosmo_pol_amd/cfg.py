@@ -78,6 +78,12 @@ def init(options_file):
             if message:
                 print(message)
             conf[section][key] = value
+    if conf['integration']['antenna_diagram'] != '':
+        # utilities/cfg.py:154-163: fit a sum of Gaussians to the antenna diagram (used by integration scheme 2)
+        from .quadrature import optimize_gaussians
+        data = np.genfromtxt(conf['integration']['antenna_diagram'], delimiter=',')
+        y = 10 * np.log10((10 ** (0.1 * data[:, 1])) ** 2)
+        conf['integration']['antenna_params'] = optimize_gaussians(data[:, 0], y, conf['integration']['n_gaussians'])
     CONFIG = conf
 
 

@@ -6,6 +6,7 @@ import numpy as np
 from . import _lib
 from . import constants as cst
 from . import hydrometeors
+from . import quadrature
 
 
 def earth_radius(latitude):
@@ -22,29 +23,8 @@ def radar_ranges(conf):
 
 
 def gauss_hermite_subbeams(conf):
-    """Sub-beams of integration scheme 1 (interpolation/interpolation.py:67-85,226-236,260-266):
-    returns (az_off, el_off, weight) of the kept points, horizontal index outer, vertical inner."""
-    bw = conf['radar']['3dB_beamwidth']
-    nh, nv = int(conf['integration']['nh_GH']), int(conf['integration']['nv_GH'])
-    sigma = bw / (2 * np.sqrt(2 * np.log(2)))
-    ph, wh = np.polynomial.hermite.hermgauss(nh)
-    pv, wv = np.polynomial.hermite.hermgauss(nv)
-    ph, pv = ph * sigma, pv * sigma                      # no sqrt(2): as the reference
-    w = np.outer(wh * sigma, wv * sigma)
-    w *= np.abs(np.cos(pv))                              # degrees fed to cos: as the reference
-    total = np.sum(w.ravel())
-    ws = np.sort(w.ravel())[::-1]
-    wc = np.cumsum(ws / total)
-    wc[-1] = 1.
-    thr = ws[np.where(wc >= conf['integration']['weight_threshold'])[0][0]]
-    total = np.sum(ws[ws >= thr])
-    broad = nh > 1 or nv > 1
-    az, el, ww = [], [], []
-    for i in range(nh):
-        for j in range(nv):
-            if w[i, j] >= thr or not broad:
-                az.append(ph[i]); el.append(pv[j]); ww.append(w[i, j] / total)
-    return np.array(az), np.array(el), np.array(ww)
+    """Sub-beams of the configured integration scheme as (az_off, el_off, weight), see quadrature.subbeam_set."""
+    return quadrature.subbeam_set(conf)
 
 
 class Engine(object):

@@ -4,6 +4,8 @@ here.  One engine per (device); model / tables are re-uploaded only when the cal
 different object."""
 import copy
 
+import numpy as np
+
 from . import cfg, engine
 
 _engines = {}
@@ -52,14 +54,10 @@ def ensure_model(st, dic_variables):
 
 
 def ensure_quadrature(st):
-    c = st.eng.conf
-    key = (c['integration']['scheme'], c['integration']['nh_GH'], c['integration']['nv_GH'],
-           c['integration']['weight_threshold'], c['radar']['3dB_beamwidth'])
+    integ = st.eng.conf['integration']
+    key = (repr(sorted((k, np.asarray(v).tolist()) for k, v in integ.items())), st.eng.conf['radar']['3dB_beamwidth'])
     if st.quad_key != key:
-        if c['integration']['scheme'] != 1:
-            raise NotImplementedError("only integration scheme 1 (Gauss-Hermite) generates its own sub-beams; "
-                                      "pass other point sets through Engine.ctx.set_quadrature")
-        st.quad = st.eng.set_gauss_hermite()
+        st.quad = st.eng.set_gauss_hermite()      # every integration scheme ends in the same sub-beam list
         st.quad_key = key
     return st.quad
 

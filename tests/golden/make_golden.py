@@ -276,6 +276,90 @@ def gen_cut():
     save('cut', zh=zh, **out)
 
 
+def synthetic_antenna():
+    """One-way antenna diagram (angle in degrees, gain in dB): main lobe of 1.45 deg and two side lobes."""
+    ang = np.round(np.arange(-6., 6.0001, 0.1), 10)
+    sig = 1.45 / (2 * np.sqrt(2 * np.log(2)))
+    lin = np.exp(-ang ** 2 / (2 * sig ** 2)) + 10 ** -2.6 * np.exp(-(np.abs(ang) - 2.8) ** 2 / (2 * 0.4 ** 2)) \
+        + 10 ** -3.3 * np.exp(-(np.abs(ang) - 4.9) ** 2 / (2 * 0.5 ** 2))
+    return ang, 10 * np.log10(lin) / 2.          # the reference squares the one-way gain (interpolation.py:124)
+
+
+PROFILE_CASES = {
+    'gh_1x1': dict(integration={'scheme': 1, 'nh_GH': 1, 'nv_GH': 1, 'weight_threshold': 1.}),
+    'gh_3x3': dict(integration={'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.}),
+    'gh_3x9_thr': dict(integration={'scheme': 1, 'nh_GH': 3, 'nv_GH': 9, 'weight_threshold': 0.999}),
+    'multigauss': dict(integration={'scheme': 2, 'nr_GH': 3, 'na_GL': 5, 'weight_threshold': 1.,
+                                    'antenna_params': np.array([[0., 0., 0.62], [-26., 2.8, 0.4], [-26., -2.8, 0.4]])}),
+    'legendre_antenna': dict(integration={'scheme': 3, 'nh_GH': 5, 'nv_GH': 3, 'weight_threshold': 1.}),
+    'gautschi': dict(integration={'scheme': 5, 'nh_GH': 3, 'nv_GH': 5, 'weight_threshold': 0.9999}),
+}
+
+
+def gen_profiles():
+    """interpolation.get_profiles_GH run by the reference itself (geodesy through stand-ins, see
+    ref_shim.install_geo_standins): the sub-beam set of integration schemes 1, 2, 3 and 5 and the
+    assembled beams on a small model."""
+    import tempfile
+    from oracle import cosmo_oracle as O
+    m = syn.synthetic_model(nz=16, ny=60, nx=64, scheme=1, seed=5, llc=(-1.6, -1.5), res=(0.05, 0.05),
+                            pole=(-44.0, 8.5), ztop=12000.)
+    attrs = {'z-levels': m['zlev'], 'proj_info': m['proj_info'], 'resolution': m['resolution']}
+    ang, gain_db = synthetic_antenna()
+    tmp = tempfile.NamedTemporaryFile('w', suffix='.csv', delete=False)
+    np.savetxt(tmp, np.column_stack((ang, gain_db)), delimiter=',')
+    tmp.close()
+    out = {'antenna_angles': ang, 'antenna_db': gain_db, 'names': np.array(sorted(PROFILE_CASES))}
+    az, el = 123.0, 4.0
+    for name in sorted(PROFILE_CASES):
+        ov = copy.deepcopy(PROFILE_CASES[name])
+        if ov['integration']['scheme'] in (3, 5):
+            ov['integration']['antenna_diagram'] = tmp.name
+        ov['radar'] = {'coords': [46.0, 8.5, 1500.], 'radial_resolution': 500., 'range': 20000.,
+                       'frequency': 5.6, '3dB_beamwidth': 1.45}
+        cfg, constants = ref_shim.install(ov)
+        ref_shim.install_geo_standins()
+        from cosmo_pol.interpolation import interpolation
+        # an ordered mapping in the variable order the operator loads (radar_operator.py:32)
+        dic = {n: O.ModelVar(m['fields'][n], attrs) for n in m['names']}
+        with np.errstate(all='ignore'):
+            beams = interpolation.get_profiles_GH(dic, az, el)
+        out[name + '_GH_pt'] = np.array([b.GH_pt for b in beams], dtype=np.float64)
+        out[name + '_GH_weight'] = np.array([b.GH_weight for b in beams], dtype=np.float64)
+        out[name + '_mask'] = np.stack([b.mask for b in beams])
+        out[name + '_elev'] = np.stack([b.elev_profile for b in beams])
+        out[name + '_dist'] = np.stack([b.dist_profile for b in beams])
+        out[name + '_heights'] = np.stack([b.heights_profile for b in beams])
+        for v in ('T', 'QR_v', 'U'):
+            out[name + '_val_' + v] = np.stack([b.values[v] for b in beams])
+        print(name, len(beams), 'sub-beams, weight sum', out[name + '_GH_weight'].sum())
+    os.unlink(tmp.name)
+    out['azimuth'], out['elevation'] = az, el
+    save('profiles', **out)
+
+
+def gen_quadrature():
+    """quadrature.get_points_and_weights (discrete Gautschi) and utilities.vector_1d_to_polar."""
+    ref_shim.install()
+    import scipy.interpolate as interp
+    from cosmo_pol.interpolation import quadrature
+    from cosmo_pol.utilities import utilities
+    ang, gain_db = synthetic_antenna()
+    power_sq = (10 ** (0.1 * gain_db)) ** 2
+    out = {'antenna_angles': ang, 'antenna_db': gain_db}
+    fit = interp.interp1d(ang, power_sq, fill_value=0)
+    for n in (1, 3, 5, 9):
+        pts, w = quadrature.get_points_and_weights(fit, -ang.max(), ang.max(), n)
+        out['gautschi_pts_%d' % n], out['gautschi_w_%d' % n] = pts, w
+    pts, w = quadrature.get_points_and_weights(num_points=4)
+    out['legendre_pts_4'], out['legendre_w_4'] = pts, w
+    x = np.polynomial.legendre.leggauss(5)[0] * ang.max()
+    y = np.polynomial.legendre.leggauss(3)[0] * ang.max()
+    out['polar_x'], out['polar_y'] = x, y
+    out['polar'] = utilities.vector_1d_to_polar(ang, power_sq, x, y)
+    save('quadrature', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for n in sys.argv[1:]:
@@ -290,3 +374,5 @@ if __name__ == '__main__':
     gen_interp()
     gen_refl()
     gen_cut()
+    gen_quadrature()
+    gen_profiles()

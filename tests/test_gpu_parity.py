@@ -518,3 +518,41 @@ def test_reference_configuration(name):
             n_moved = check_spectrum(sp[okr], ws[okr])
         rv = radar.fields['RVEL']['data'][0].filled(np.nan)
         util.assert_close(rv, want.values['RVEL'], rtol=1e-5, atol=0.02 if n_moved else 1e-6, name='RVEL')
+
+
+@pytest.mark.parametrize('name', ['gh_1x1', 'gh_3x3', 'gh_3x9_thr', 'multigauss', 'legendre_antenna', 'gautschi'])
+def test_profiles_vs_reference_run(name, tmp_path):
+    """interpolation.get_profiles_GH against the beams the reference's own get_profiles_GH assembled (golden
+    'profiles': integration schemes 1, 2, 3, 5; geodesy served by stand-ins there, so positions are not pinned by
+    it, but the sub-beam set, refraction, masks and the interpolated values along the beams are)."""
+    from cosmo_pol_amd import interpolation, cfg as pcfg, model as pmodel, runtime
+    from cosmo_pol_amd.constants import constants
+    from tests.golden.make_golden import PROFILE_CASES
+    g = util.golden('profiles')
+    conf = O.make_config(radar={'coords': [46.0, 8.5, 1500.], 'radial_resolution': 500., 'range': 20000.,
+                                'frequency': 5.6, '3dB_beamwidth': 1.45},
+                         integration=dict(PROFILE_CASES[name]['integration']))
+    if conf['integration']['scheme'] in (3, 5):
+        path = str(tmp_path / 'antenna.csv')
+        np.savetxt(path, np.column_stack((g['antenna_angles'], g['antenna_db'])), delimiter=',')
+        conf['integration']['antenna_diagram'] = path
+    runtime.reset()
+    pcfg.set_config(conf)
+    constants.update()
+    m = pipeline_model(1)
+    dic = pmodel.variables_from_arrays(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    beams = interpolation.get_profiles_GH(dic, float(g['azimuth']), float(g['elevation']))
+    assert len(beams) == len(g[name + '_GH_weight'])
+    n_ulp = 0
+    for b, bm in enumerate(beams):
+        np.testing.assert_allclose(bm.GH_pt, g[name + '_GH_pt'][b], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(bm.GH_weight, g[name + '_GH_weight'][b], rtol=1e-9)
+        np.testing.assert_array_equal(bm.mask, g[name + '_mask'][b])
+        for got, want in ((bm.dist_profile, g[name + '_dist'][b]), (bm.heights_profile, g[name + '_heights'][b]),
+                          (bm.elev_profile, g[name + '_elev'][b])):
+            d = np.abs(got.view(np.int32) - want.view(np.int32))
+            assert d.max() <= 1
+            n_ulp += int((d != 0).sum())
+        for v in ('T', 'QR_v', 'U'):
+            util.assert_close(bm.values[v], g['%s_val_%s' % (name, v)][b], rtol=2e-5, atol=1e-12, name=v)
+    assert n_ulp <= 0.002 * 3 * len(beams) * len(beams[0].dist_profile) + 1

@@ -3,11 +3,13 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from cosmo_pol_amd import _lib, cfg, engine, hydrometeors
 from oracle import cosmo_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
 def test_library_exports_every_declared_symbol():
@@ -50,3 +52,74 @@ def test_cfg_defaults_and_unknown_keys(tmp_path):
     assert cfg.CONFIG['microphysics']['scheme'] == 1
     cfg.init(str(tmp_path / 'missing.yml'))
     assert cfg.CONFIG == cfg.DEFAULTS
+
+
+# ---------------------------------------------------------------------------------------------
+# antenna quadrature (integration schemes 1, 2, 3, 5) against the reference's own run
+# ---------------------------------------------------------------------------------------------
+def _write_antenna(tmp_path, g):
+    path = str(tmp_path / 'antenna.csv')
+    np.savetxt(path, np.column_stack((g['antenna_angles'], g['antenna_db'])), delimiter=',')
+    return path
+
+
+def test_gautschi_quadrature_vs_golden():
+    """quadrature.get_points_and_weights and utilities.vector_1d_to_polar as run by the reference."""
+    import scipy.interpolate as interp
+    from cosmo_pol_amd import quadrature
+    g = np.load(os.path.join(GOLDEN, 'quadrature.npz'))
+    ang = g['antenna_angles']
+    power_sq = (10 ** (0.1 * g['antenna_db'])) ** 2
+    fit = interp.interp1d(ang, power_sq, fill_value=0)
+    for n in (1, 3, 5, 9):
+        pts, w = quadrature.get_points_and_weights(fit, -ang.max(), ang.max(), n)
+        np.testing.assert_allclose(pts, g['gautschi_pts_%d' % n], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(w, g['gautschi_w_%d' % n], rtol=1e-9, atol=1e-14)
+    pts, w = quadrature.get_points_and_weights(num_points=4)
+    np.testing.assert_allclose(pts, g['legendre_pts_4'], atol=1e-12)
+    np.testing.assert_allclose(w, g['legendre_w_4'], rtol=1e-10)
+    pol = quadrature.vector_1d_to_polar(ang, power_sq, g['polar_x'], g['polar_y'])
+    np.testing.assert_allclose(pol, g['polar'], rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize('name', ['gh_1x1', 'gh_3x3', 'gh_3x9_thr', 'multigauss', 'legendre_antenna', 'gautschi'])
+def test_subbeam_set_vs_reference(name, tmp_path):
+    """The sub-beam list (points, weights, order, thresholding) of get_profiles_GH as the reference builds it
+    (interpolation.py:66-236, 260-266, 287-305)."""
+    from cosmo_pol_amd import quadrature
+    from tests.golden.make_golden import PROFILE_CASES
+    g = np.load(os.path.join(GOLDEN, 'profiles.npz'))
+    conf = O.make_config(radar={'3dB_beamwidth': 1.45}, integration=dict(PROFILE_CASES[name]['integration']))
+    if conf['integration']['scheme'] in (3, 5):
+        conf['integration']['antenna_diagram'] = _write_antenna(tmp_path, g)
+    az, el, w = quadrature.subbeam_set(conf)
+    pts = g[name + '_GH_pt']
+    assert len(w) == len(pts)
+    np.testing.assert_allclose(az + float(g['azimuth']), pts[:, 0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(el + float(g['elevation']), pts[:, 1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(w, g[name + '_GH_weight'], rtol=1e-9, atol=1e-15)
+
+
+def test_oracle_gh_quadrature_vs_reference():
+    """The oracle's own scheme-1 set-up against the same run."""
+    g = np.load(os.path.join(GOLDEN, 'profiles.npz'))
+    from tests.golden.make_golden import PROFILE_CASES
+    for name in ('gh_1x1', 'gh_3x3', 'gh_3x9_thr'):
+        conf = O.make_config(radar={'3dB_beamwidth': 1.45}, integration=dict(PROFILE_CASES[name]['integration']))
+        subs, _ = O.gh_quadrature(conf)
+        np.testing.assert_allclose([s[2] + float(g['azimuth']) for s in subs], g[name + '_GH_pt'][:, 0], atol=1e-12)
+        np.testing.assert_allclose([s[3] + float(g['elevation']) for s in subs], g[name + '_GH_pt'][:, 1], atol=1e-12)
+        np.testing.assert_allclose([s[4] for s in subs], g[name + '_GH_weight'], rtol=1e-13)
+
+
+def test_antenna_fit_recovers_gaussians():
+    """optimize_gaussians (antenna_fit.py:36-67; it cannot run under Python 3 in the reference because of an
+    integer division, so no golden): a diagram that IS a sum of Gaussians is fitted back to within 0.3 dB."""
+    from cosmo_pol_amd import quadrature
+    x = np.round(np.arange(-6., 6.0001, 0.1), 10)
+    true = np.array([[0., 0., 0.62], [-26., 2.8, 0.4], [-26., -2.8, 0.4]])
+    y = quadrature.gaussian_sum(x, true)
+    p = quadrature.optimize_gaussians(x, y, 3)
+    assert p.shape == (3, 3) and p[0, 0] == 0 and p[0, 1] == 0
+    main = np.abs(x) < 1.5
+    assert np.abs(quadrature.gaussian_sum(x, p) - y)[main].max() < 0.3
