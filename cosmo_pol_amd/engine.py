@@ -71,7 +71,7 @@ class Engine(object):
         for h in hydrometeors.hydrom_types(scheme):
             lut = lut_sz[h]
             ie, it, idd = lut.axes_names['e'], lut.axes_names['t'], lut.axes_names['d']
-            tab = np.asarray(lut.value_table)
+            tab = lut.float_table() if getattr(lut, 'int_transform', False) else np.asarray(lut.value_table)
             order = (ie, it, idd, lut.axes_names['sz'])
             if order != (0, 1, 2, 3):
                 tab = np.transpose(tab, order)

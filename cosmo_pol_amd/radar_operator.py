@@ -42,11 +42,11 @@ class RadarOperator(object):
         constants.update()
 
     def set_lut(self, hydro_scheme, lut=None):
-        """lut: {class letter: Lookup_table}.  The reference reads gzip-pickled tables from
-        lookup/final_lut (lookup/read_lut.py:10-20); those files are not part of its repository, so the
-        tables have to be supplied by the caller."""
+        """lut: {class letter: Lookup_table}; without it the tables of the configured frequency are read from
+        read_lut.FOLDER_LUT like lookup/read_lut.py:10-20 does (flat .clut files, see read_lut)."""
         if lut is None:
-            raise ValueError("set_lut needs the lookup tables: {'R': Lookup_table, 'S': ..., 'G': ...[, 'H': ...]}")
+            from . import read_lut
+            lut = read_lut.get_lookup_tables(hydro_scheme, cfg.CONFIG['radar']['frequency'])
         self.lut_sz = lut
 
     def get_pos_and_time(self):
@@ -112,7 +112,9 @@ class RadarOperator(object):
         ranges = st.eng.n_gates and np.arange(cfg.CONFIG['radar']['radial_resolution'] / 2,
                                               cfg.CONFIG['radar']['range'], cfg.CONFIG['radar']['radial_resolution'])
         return SimulatedRadar(scan_type, els, azs, ranges, fields, extra['mask'], extra['lat'], extra['lon'],
-                              extra['height'], n_sweeps, rays_per_sweep, self.get_pos_and_time())
+                              extra['height'], n_sweeps, rays_per_sweep, self.get_pos_and_time(),
+                              fixed_angles=sweep_elev if scan_type == 'ppi' else sweep_az,
+                              varray=constants.VARRAY)
 
     def get_PPI(self, elevations, azimuths=[], az_step=-1, az_start=0, az_stop=359):
         """radar_operator.py:195-273."""

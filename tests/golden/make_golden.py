@@ -360,6 +360,36 @@ def gen_quadrature():
     save('quadrature', **out)
 
 
+def gen_lutpack():
+    """lookup/lut.py: int16 packing (float_to_uint16 / get_float_data), lookup_pts, lookup_line on a small table."""
+    ref_shim.install()
+    from cosmo_pol.lookup.lut import Lookup_table
+    rng = np.random.default_rng(77)
+    e, t, d = np.arange(0, 8, 2.), np.arange(262, 272, 2.), np.linspace(0.2, 8, 6).astype('float32')
+    tab = (10 ** rng.uniform(-6, 1, (4, 5, 6, 12))) * rng.choice([-1, 1], (4, 5, 6, 12))
+    tab[1, 2, 3, 4] = np.nan
+    tab[0, 0, 0, 0] = np.inf
+    out = {'e': e, 't': t, 'd': d, 'table': tab.copy()}
+    coords = np.vstack([rng.uniform(0, 6, 40), rng.uniform(262, 270, 40), rng.uniform(0.2, 8, 40), rng.integers(0, 12, 40)])
+    out['coords'] = coords
+    for packed in (False, True):
+        lut = Lookup_table()
+        lut.add_axis('e', e); lut.add_axis('t', t); lut.add_axis('d', d); lut.add_axis('sz', np.arange(12))
+        with np.errstate(all='ignore'):
+            lut.set_value_table(tab.copy(), map_to_int=packed)
+            pts = lut.lookup_pts(coords.copy())
+            line = lut.lookup_line(e=np.array([1.0, 3.0, 5.1]), t=np.array([263.0, 265.0, 270.0]))
+        tag = 'packed' if packed else 'plain'
+        out['pts_' + tag] = pts
+        out['line_' + tag] = line
+        if packed:
+            out['int16'] = lut.value_table
+            out['range'] = np.array(lut.range_orig_data)
+            with np.errstate(all='ignore'):
+                out['unpacked'] = lut.get_float_data(lut.value_table)
+    save('lutpack', **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:
         for n in sys.argv[1:]:
@@ -376,3 +406,4 @@ if __name__ == '__main__':
     gen_cut()
     gen_quadrature()
     gen_profiles()
+    gen_lutpack()

@@ -123,3 +123,130 @@ def test_antenna_fit_recovers_gaussians():
     assert p.shape == (3, 3) and p[0, 0] == 0 and p[0, 1] == 0
     main = np.abs(x) < 1.5
     assert np.abs(quadrature.gaussian_sum(x, p) - y)[main].max() < 0.3
+
+
+# ---------------------------------------------------------------------------------------------
+# output container (radar/pyart_wrapper.py:107-232 without PyART)
+# ---------------------------------------------------------------------------------------------
+def _toy_radar(scan_type='ppi'):
+    from cosmo_pol_amd.radar_output import SimulatedRadar
+    rng = np.random.default_rng(0)
+    n_sw, n_ray, n_g = 2, 3, 5
+    zh = (10 ** rng.uniform(-1, 4, (n_sw * n_ray, n_g))).astype('float32')
+    zh[0, 0] = 0.
+    zh[1, 2] = np.nan
+    fields = {'ZH': zh, 'ZDR': np.full_like(zh, 1.3), 'KDP': rng.normal(size=zh.shape).astype('float32'),
+              'DSPECTRUM': rng.uniform(size=zh.shape + (4,))}
+    lat = rng.uniform(45, 47, zh.shape)
+    els = np.repeat([1.0, 2.5], n_ray) if scan_type == 'ppi' else np.tile([1., 2., 3.], n_sw)
+    azs = np.tile([0., 120., 240.], n_sw) if scan_type == 'ppi' else np.repeat([10., 190.], n_ray)
+    r = SimulatedRadar(scan_type, els, azs, 250. + 500. * np.arange(n_g), fields, np.zeros(zh.shape), lat, lat + 1,
+                       np.zeros(zh.shape), n_sw, n_ray, {'latitude': 46., 'longitude': 8., 'altitude': 1600., 'time': 0},
+                       varray=np.linspace(-1, 1, 4))
+    return r, zh
+
+
+def test_simulated_radar_fields():
+    r, zh = _toy_radar('ppi')
+    d = r.fields['ZH']['data']
+    # 0 -> NaN before the dB conversion, NaN masked (pyart_wrapper.py:159-161,193-195)
+    assert d.mask[0, 0] and d.mask[1, 2] and d.mask.sum() == 2
+    np.testing.assert_allclose(d[0, 1], 10 * np.log10(zh[0, 1]), rtol=1e-6)
+    np.testing.assert_allclose(r.fields['ZDR']['data'][2, 2], 10 * np.log10(1.3), rtol=1e-6)
+    assert r.fields['ZH']['units'] == 'dBZ' and r.fields['ZH']['valid_max'] == 55
+    assert r.fields['KDP']['long_name'] == 'Specific diff. phase'
+    assert r.fields['DSPECTRUM']['data'].shape == (6, 5, 4)            # stays linear
+    assert r.fields['range']['data'].shape == (6, 5) and r.fields['Latitude']['data'].shape == (6, 5)
+    np.testing.assert_array_equal(r.fixed_angle['data'], [1.0, 2.5])
+    np.testing.assert_array_equal(r.sweep_start_ray_index['data'], [0, 3])
+    np.testing.assert_array_equal(r.sweep_end_ray_index['data'], [2, 5])
+    assert r.get_field(1, 'ZH').shape == (3, 5)
+    np.testing.assert_array_equal(r.get_azimuth(1), [0., 120., 240.])
+    rr, _ = _toy_radar('rhi')
+    np.testing.assert_array_equal(rr.fixed_angle['data'], [10., 190.])
+
+
+def test_simulated_radar_netcdf_roundtrip(tmp_path):
+    from scipy.io import netcdf_file
+    r, zh = _toy_radar('ppi')
+    path = str(tmp_path / 'scan.nc')
+    r.to_netcdf(path)
+    with netcdf_file(path, 'r', mmap=False) as nc:
+        assert nc.dimensions['time'] == 6 and nc.dimensions['range'] == 5 and nc.dimensions['sweep'] == 2
+        np.testing.assert_array_equal(nc.variables['azimuth'][:], r.azimuth['data'])
+        np.testing.assert_array_equal(nc.variables['fixed_angle'][:], [1.0, 2.5])
+        z = nc.variables['ZH'][:].copy()
+        assert z[0, 0] == np.float32(-9999.) and z[1, 2] == np.float32(-9999.)
+        np.testing.assert_allclose(z[0, 1], 10 * np.log10(zh[0, 1]), rtol=1e-6)
+        assert nc.variables['ZH'].units == b'dBZ'
+        assert nc.variables['DSPECTRUM'][:].shape == (6, 5, 4)
+        assert float(nc.variables['altitude'].getValue()) == 1600.
+
+
+# ---------------------------------------------------------------------------------------------
+# lookup-table container and files (lookup/lut.py, lookup/read_lut.py)
+# ---------------------------------------------------------------------------------------------
+def _golden_lut(g, packed):
+    from cosmo_pol_amd.lut import Lookup_table
+    lut = Lookup_table()
+    lut.add_axis('e', g['e']); lut.add_axis('t', g['t']); lut.add_axis('d', g['d']); lut.add_axis('sz', np.arange(12))
+    with np.errstate(all='ignore'):
+        lut.set_value_table(g['table'].copy(), map_to_int=packed)
+    return lut
+
+
+def test_lut_packing_and_lookups_vs_reference():
+    g = np.load(os.path.join(GOLDEN, 'lutpack.npz'))
+    with np.errstate(all='ignore'):
+        plain, packed = _golden_lut(g, False), _golden_lut(g, True)
+        np.testing.assert_array_equal(packed.value_table, g['int16'])
+        np.testing.assert_array_equal(packed.range_orig_data, g['range'])
+        np.testing.assert_array_equal(packed.get_float_data(packed.value_table), g['unpacked'])
+        np.testing.assert_array_equal(plain.lookup_pts(g['coords'].copy()), g['pts_plain'])
+        np.testing.assert_array_equal(packed.lookup_pts(g['coords'].copy()), g['pts_packed'])
+    kw = dict(e=np.array([1.0, 3.0, 5.1]), t=np.array([263.0, 265.0, 270.0]))
+    np.testing.assert_array_equal(plain.lookup_line(**kw), g['line_plain'])
+    np.testing.assert_array_equal(packed.lookup_line(**kw), g['line_packed'])
+
+
+def test_lut_file_roundtrip_and_frequency_interpolation(tmp_path):
+    from cosmo_pol_amd import read_lut, synthetic as syn
+    from cosmo_pol_amd.lut import Lookup_table
+    folder = str(tmp_path)
+    tabs = {}
+    for f in (5.6, 7.7):
+        tabs[f] = {h: Lookup_table.from_arrays(*syn.synthetic_lut(h, f, n_e=3, n_t=4)) for h in ('R', 'S', 'G')}
+        read_lut.save_lookup_tables(read_lut.lut_filename(1, f, folder), tabs[f], frequency=f, scheme=1)
+    got = read_lut.get_lookup_tables('1mom', 5.6, folder=folder)
+    assert sorted(got) == ['G', 'R', 'S']
+    for h in got:
+        assert isinstance(got[h].value_table, np.memmap)
+        np.testing.assert_array_equal(got[h].value_table, tabs[5.6][h].value_table)
+        assert got[h].axes_names == tabs[5.6][h].axes_names
+        for a, b in zip(got[h].axes, tabs[5.6][h].axes):
+            np.testing.assert_array_equal(a, b)
+        assert got[h].axes_step == tabs[5.6][h].axes_step
+    # a frequency without a file: linear interpolation between its neighbours, stored for the next call
+    mid = read_lut.get_lookup_tables(1, 6.5, folder=folder)
+    assert os.path.exists(read_lut.lut_filename(1, 6.5, folder))
+    t1, t2 = tabs[5.6]['R'].value_table.astype(np.float64), tabs[7.7]['R'].value_table.astype(np.float64)
+    np.testing.assert_allclose(mid['R'].value_table, t1 + (t2 - t1) / (7.7 - 5.6) * (6.5 - 5.6), rtol=1e-6)
+    with pytest.raises(ValueError):
+        read_lut.get_lookup_tables(1, 1.0, folder=folder)
+    # int16 storage
+    p = str(tmp_path / 'packed.clut')
+    read_lut.save_lookup_tables(p, {'R': tabs[5.6]['R']}, pack_int16=True)
+    back = read_lut.load_lookup_tables(p)['R']
+    assert back.int_transform and back.value_table.dtype == np.int16
+    ft = back.float_table()
+    rng_ = tabs[5.6]['R'].value_table.max() - tabs[5.6]['R'].value_table.min()
+    assert np.abs(ft - tabs[5.6]['R'].value_table).max() <= rng_ / 65534. * 1.01
+    # plain-array export
+    d = tmp_path / 'arrays'
+    d.mkdir()
+    e, t, dd, tab = syn.synthetic_lut('R', 5.6, n_e=3, n_t=4)
+    for n, a in (('e', e), ('t', t), ('d', dd), ('table', tab)):
+        np.save(str(d / ('R_%s.npy' % n)), a)
+    arr = read_lut.from_arrays_dir(str(d))
+    assert list(arr) == ['R']
+    np.testing.assert_array_equal(arr['R'].value_table, tab)
