@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcosmopol_hip.so")
 
-OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_DOMAIN = 0, 1, 2, 3, 4
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_DOMAIN, ERR_REFRACTION = 0, 1, 2, 3, 4, 5
 N_OBS = 9
 OBS_NAMES = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'AH', 'AV']
 VAR_SLOTS = {'U': 0, 'V': 1, 'W': 2, 'QR_v': 3, 'QS_v': 4, 'QG_v': 5, 'RHO': 6, 'T': 7,
@@ -55,7 +55,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -88,6 +88,7 @@ def load():
     lib.cpol_upload_lut.argtypes = [vp, C.c_int, C.POINTER(CpolLut), C.POINTER(CpolPsd), C.POINTER(CpolPsd)]
     lib.cpol_set_quadrature.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p]
     lib.cpol_set_velocity_bins.argtypes = [vp, C.c_int, c_double_p]
+    lib.cpol_set_refraction_table.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_float_p, c_float_p]
     lib.cpol_run_rays.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_run_rays_dev.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_geolocate.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_float_p, c_float_p, c_float_p,
@@ -237,6 +238,18 @@ class Context(object):
         self._check(self.lib.cpol_set_velocity_bins(self.h, len(v), dptr(v)), 'cpol_set_velocity_bins')
         self.n_vel = len(v)
 
+    def set_refraction_table(self, keys=None, S=None, H=None, E=None):
+        """keys: ascending total elevations; S, H, E: [len(keys), n_gates].  No arguments: back to the 4/3 model."""
+        if keys is None or len(keys) == 0:
+            self._check(self.lib.cpol_set_refraction_table(self.h, 0, None, None, None, None), 'cpol_set_refraction_table')
+            return
+        k = np.ascontiguousarray(keys, dtype=np.float64)
+        S, H, E = (np.ascontiguousarray(a, dtype=np.float32) for a in (S, H, E))
+        if not (S.shape == H.shape == E.shape == (len(k), self.n_gates)):
+            raise ValueError('refraction profiles must be [%d, %d]' % (len(k), self.n_gates))
+        self._check(self.lib.cpol_set_refraction_table(self.h, len(k), dptr(k), fptr(S), fptr(H), fptr(E)),
+                    'cpol_set_refraction_table')
+
     def set_quadrature(self, az_off, el_off, weight):
         a = np.ascontiguousarray(az_off, dtype=np.float64)
         e = np.ascontiguousarray(el_off, dtype=np.float64)
@@ -264,6 +277,8 @@ class Context(object):
         self._check(rc, 'cpol_run_rays')
         if raise_on_domain and (out['ray_status'] == ERR_DOMAIN).any():
             self._check(ERR_DOMAIN, 'cpol_run_rays')
+        if (out['ray_status'] == ERR_REFRACTION).any():
+            raise CosmoPolError('cpol_run_rays: the refraction table has no profile for the elevation of some rays')
         return out
 
     def run_rays_dev(self, az_ptr, el_ptr, n_rays, outputs=None):

@@ -133,6 +133,8 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->dcol) hipFree(ctx->dcol);
     if (ctx->quad_dev) hipFree(ctx->quad_dev);
     if (ctx->varray_dev) hipFree(ctx->varray_dev);
+    if (ctx->refr_keys) hipFree(ctx->refr_keys);
+    if (ctx->refr_tab) hipFree(ctx->refr_tab);
     if (ctx->rawptr_dev) hipFree((void *)ctx->rawptr_dev);
     for (auto &l : ctx->lut) {
         float *owned[] = {l.raw, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
@@ -268,6 +270,32 @@ extern "C" int cpol_set_velocity_bins(cpol_ctx *ctx, int n_vel, const double *va
     HIPCHK(ctx, hipMalloc((void **)&ctx->varray_dev, n_vel * sizeof(double)));
     HIPCHK(ctx, hipMemcpy(ctx->varray_dev, varray, n_vel * sizeof(double), hipMemcpyDefault));
     ctx->n_vel = n_vel;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_set_refraction_table(cpol_ctx *ctx, int n_profiles, const double *keys, const float *S,
+                                         const float *H, const float *E)
+{
+    if (!ctx || n_profiles < 0) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->refr_keys) { HIPCHK(ctx, hipFree(ctx->refr_keys)); ctx->refr_keys = nullptr; }
+    if (ctx->refr_tab) { HIPCHK(ctx, hipFree(ctx->refr_tab)); ctx->refr_tab = nullptr; }
+    ctx->n_refr = 0;
+    if (n_profiles == 0) return CPOL_OK;
+    if (!ctx->have_cfg) return fail(ctx, CPOL_ERR_STATE, "cpol_set_config has not been called");
+    if (!keys || !S || !H || !E) return fail(ctx, CPOL_ERR_ARG, "refraction table: NULL array");
+    for (int i = 1; i < n_profiles; i++)
+        if (!(keys[i] > keys[i - 1])) return fail(ctx, CPOL_ERR_ARG, "refraction table: keys must be strictly ascending");
+    const size_t G = ctx->cfg.n_gates, n = (size_t)n_profiles * G;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->refr_keys, n_profiles * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->refr_tab, 3 * n * sizeof(float)));
+    HIPCHK(ctx, hipMemcpy(ctx->refr_keys, keys, n_profiles * sizeof(double), hipMemcpyDefault));
+    HIPCHK(ctx, hipMemcpy(ctx->refr_tab, S, n * sizeof(float), hipMemcpyDefault));
+    HIPCHK(ctx, hipMemcpy(ctx->refr_tab + n, H, n * sizeof(float), hipMemcpyDefault));
+    HIPCHK(ctx, hipMemcpy(ctx->refr_tab + 2 * n, E, n * sizeof(float), hipMemcpyDefault));
+    ctx->n_refr = n_profiles;
+    ctx->refr_gates = (int)G;
     return CPOL_OK;
 }
 
@@ -493,6 +521,8 @@ static int check_ready(cpol_ctx *ctx, bool need_model, bool need_quad)
 {
     if (!ctx) return CPOL_ERR_ARG;
     if (!ctx->have_cfg) return fail(ctx, CPOL_ERR_STATE, "cpol_set_config has not been called");
+    if (ctx->n_refr > 0 && ctx->refr_gates != ctx->cfg.n_gates)
+        return fail(ctx, CPOL_ERR_STATE, "the refraction table was built for a different number of gates");
     if (need_model && !ctx->have_model) return fail(ctx, CPOL_ERR_STATE, "no model uploaded");
     if (need_quad && ctx->n_sub < 1) return fail(ctx, CPOL_ERR_STATE, "cpol_set_quadrature has not been called");
     return CPOL_OK;
@@ -504,6 +534,9 @@ static void geom_params(const cpol_ctx *ctx, GeomParams &gp)
     gp.res = ctx->cfg.range_res; gp.earth_radius = ctx->cfg.earth_radius;
     gp.pole_lat_s = ctx->pole[0]; gp.pole_lon_s = ctx->pole[1];
     gp.n_gates = ctx->cfg.n_gates; gp.n_sub = ctx->n_sub;
+    gp.n_refr = ctx->n_refr; gp.refr_keys = ctx->refr_keys;
+    const size_t n = (size_t)ctx->n_refr * ctx->refr_gates;
+    gp.refr_S = ctx->refr_tab; gp.refr_H = ctx->refr_tab + n; gp.refr_E = ctx->refr_tab + 2 * n;
 }
 
 static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)

@@ -78,6 +78,10 @@ struct GeomParams {
     double earth_radius;           // get_earth_radius(coords[1]) (atm_refraction.py:114-117)
     double pole_lat_s, pole_lon_s;
     int    n_gates, n_sub;
+    // refraction table (scheme 2): sorted total elevations and their (S, H, E) profiles; n_refr = 0 -> 4/3 model
+    int    n_refr;
+    const double *refr_keys;
+    const float  *refr_S, *refr_H, *refr_E;
 };
 
 struct ObsParams {
@@ -108,6 +112,10 @@ struct cpol_ctx {
     int n_vel = 0;                 // Doppler spectrum bins (constants.py:75 VARRAY)
     double *varray_dev = nullptr;
     const float **rawptr_dev = nullptr;   // [2][CPOL_MAX_CLASSES]: raw tables, diameter axes
+    int n_refr = 0;                       // refraction table (cpol_set_refraction_table)
+    double *refr_keys = nullptr;
+    float *refr_tab = nullptr;            // [3][n_refr][n_gates]: S, H, E
+    int refr_gates = 0;
     // grow-only device workspaces
     struct Buf { void *p = nullptr; size_t cap = 0; };
     std::vector<Buf *> bufs;

@@ -118,7 +118,8 @@ __constant__ double c_C3[45] = {3, 128, 2, 5, 128, -1, 3, 3, 64, -1, 0, 1, 8, -1
 
 // One thread per (ray, sub-beam): constants of the geodesic line through the radar.
 __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict__ az, const double *__restrict__ el,
-                            const double *__restrict__ quad, double *__restrict__ line, double *__restrict__ phi)
+                            const double *__restrict__ quad, double *__restrict__ line, double *__restrict__ phi,
+                            int *__restrict__ status)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_rays * gp.n_sub) return;
@@ -203,6 +204,16 @@ __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict_
     for (int l = 1; l <= 6; ++l) L[12 + l] = C1pa[l];
     for (int l = 1; l <= 5; ++l) L[18 + l] = C3a[l];
     L[24] = el_b;
+    if (gp.n_refr > 0) {
+        // profile of this total elevation in the refraction table (exact key)
+        int lo = 0, hi = gp.n_refr - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (gp.refr_keys[mid] < el_b) lo = mid + 1; else hi = mid;
+        }
+        if (gp.refr_keys[lo] == el_b) L[25] = (double)lo;
+        else { L[25] = -1.; status[r] = CPOL_ERR_REFRACTION; }
+    }
 }
 
 // One thread per (ray, sub-beam, gate).
@@ -217,17 +228,25 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     long rb = u / gp.n_gates;
     const double *L = line + rb * LINE_N;
 
-    // ---- refraction, 4/3 earth model (atm_refraction.py:110-123) ----
-    double rr = gp.res / 2 + g * gp.res;                 // np.arange(res/2, range, res)
-    double ela = L[24] * M_PI / 180.;
-    double sel = sin(ela), cel = cos(ela);
-    const double ke = 4. / 3.;
-    double keR = ke * gp.earth_radius;
-    double Hd = sqrt(rr * rr + keR * keR + 2 * rr * ke * gp.earth_radius * sel) - keR + gp.alt;
-    double Sd = keR * asin((rr * cel) / (keR + Hd));
-    double Ed = ela + atan(rr * cel / (rr * sel + keR + gp.alt));
-    float S = (float)Sd, H = (float)Hd;
-    float E = (float)Ed * (float)(180.0 / M_PI);
+    float S, H, E;
+    if (gp.n_refr > 0) {
+        // ---- refraction table solved on the host (scheme 2, atm_refraction.py:45-84) ----
+        long p = (long)L[25];
+        if (p < 0) p = 0;                                  // ray already flagged by k_geom_line
+        S = gp.refr_S[p * gp.n_gates + g]; H = gp.refr_H[p * gp.n_gates + g]; E = gp.refr_E[p * gp.n_gates + g];
+    } else {
+        // ---- refraction, 4/3 earth model (atm_refraction.py:110-123) ----
+        double rr = gp.res / 2 + g * gp.res;                 // np.arange(res/2, range, res)
+        double ela = L[24] * M_PI / 180.;
+        double sel = sin(ela), cel = cos(ela);
+        const double ke = 4. / 3.;
+        double keR = ke * gp.earth_radius;
+        double Hd = sqrt(rr * rr + keR * keR + 2 * rr * ke * gp.earth_radius * sel) - keR + gp.alt;
+        double Sd = keR * asin((rr * cel) / (keR + Hd));
+        double Ed = ela + atan(rr * cel / (rr * sel + keR + gp.alt));
+        S = (float)Sd; H = (float)Hd;
+        E = (float)Ed * (float)(180.0 / M_PI);
+    }
     S_out[u] = S; H_out[u] = H; E_out[u] = E;
 
     // ---- geodesic position at distance S along the line ----
@@ -281,7 +300,7 @@ void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *
                  float *coords, double *phi, const ModelView &mv, int *status)
 {
     int nl = n_rays * gp.n_sub;
-    hipLaunchKernelGGL(k_geom_line, dim3((nl + 63) / 64), dim3(64), 0, s, gp, n_rays, az, el, quad, line, phi);
+    hipLaunchKernelGGL(k_geom_line, dim3((nl + 63) / 64), dim3(64), 0, s, gp, n_rays, az, el, quad, line, phi, status);
     long n_total = (long)nl * gp.n_gates;
     hipLaunchKernelGGL(k_geom_pts, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, s, gp, n_total, line,
                        S, H, E, lat, lon, coords, mv, status);

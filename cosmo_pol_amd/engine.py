@@ -63,7 +63,25 @@ class Engine(object):
     def set_gauss_hermite(self):
         az, el, w = gauss_hermite_subbeams(self.conf)
         self.ctx.set_quadrature(az, el, w)
+        self.quad = (az, el, w)
         return az, el, w
+
+    def set_refraction(self, N=None, ray_elevations=None):
+        """Refraction scheme 2: solve the ray equation through the refractivity field N (a model variable) for
+        every distinct total elevation of ray_elevations x the current sub-beams and upload the table; with
+        N = None the library returns to the 4/3 model.  Returns the number of profiles."""
+        if N is None:
+            self.ctx.set_refraction_table()
+            return 0
+        from . import refraction
+        coords = self.conf['radar']['coords']
+        el_off = np.asarray(self.quad[1], dtype=np.float64)
+        keys = np.unique((el_off[None, :] + np.asarray(ray_elevations, dtype=np.float64)[:, None]).ravel())
+        rr = radar_ranges(self.conf)
+        prof = refraction.refractive_index_profile(N, coords, self.conf['radar']['type'])
+        S, H, E = zip(*[refraction.ref_ODE_s(rr, k, coords, N, profile=prof) for k in keys])
+        self.ctx.set_refraction_table(keys, np.stack(S), np.stack(H), np.stack(E))
+        return len(keys)
 
     def upload_luts(self, lut_sz):
         """lut_sz: {class letter: Lookup_table-like with axes e, t, d, sz}."""

@@ -12,6 +12,11 @@ def get_profiles_GH(dic_variables, azimuth, elevation, radar_range=0, N=0, list_
     runtime.ensure_model(st, dic_variables)
     az_off, el_off, w = runtime.ensure_quadrature(st)
     ctx = st.eng.ctx
+    from . import cfg
+    if cfg.CONFIG['refraction']['scheme'] == 2 and N != 0:        # atm_refraction.py:32-33
+        st.eng.set_refraction(N, [float(elevation)])
+    else:
+        st.eng.set_refraction(None)
     geo = ctx.geolocate([float(azimuth)], [float(elevation)])        # raises IndexError outside the domain
     if geo['ray_status'][0] != 0:
         raise IndexError('ERROR: RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN: ABORTING')

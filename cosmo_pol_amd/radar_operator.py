@@ -65,6 +65,7 @@ class RadarOperator(object):
         two_mom = all(v in dic for v in BASE_VARIABLES_2MOM)
         names = BASE_VARIABLES + (BASE_VARIABLES_2MOM if two_mom else [])
         self.dic_vars = {k: dic[k] for k in names}
+        self.N = dic['N'] if 'N' in dic else 0          # refractivity, kept apart (radar_operator.py:141-143)
         cfg.CONFIG['microphysics']['scheme'] = 2 if two_mom else 1
         self.current_microphys_scheme = cfg.CONFIG['microphysics']['scheme']
 
@@ -86,6 +87,12 @@ class RadarOperator(object):
         runtime.ensure_model(st, self.dic_vars)
         runtime.ensure_quadrature(st)
         ctx = st.eng.ctx
+        if cfg.CONFIG['refraction']['scheme'] == 2 and self.N != 0:
+            st.eng.set_refraction(self.N, np.unique(els))
+        else:
+            if cfg.CONFIG['refraction']['scheme'] == 2:
+                print('No refractivity field N in the model state. Using 4/3 method instead.')   # radar_operator.py:99-102
+            st.eng.set_refraction(None)
         rank, world = _dist_info()
         n_total = len(azs)
         if world > 1:

@@ -23,6 +23,7 @@ extern "C" {
 #define CPOL_ERR_STATE 3      /* model / LUT / config not uploaded yet */
 #define CPOL_ERR_DOMAIN 4     /* a gate lies outside the model domain (reference: IndexError,
                                  interpolation/interpolation.py:359-363) */
+#define CPOL_ERR_REFRACTION 5 /* a sub-beam's elevation has no profile in the refraction table */
 
 #define CPOL_MAX_CLASSES 4    /* R, S, G, H (scatter/scattering_sz.py:32-35) */
 #define CPOL_MAX_VARS 16
@@ -142,6 +143,16 @@ int cpol_set_velocity_bins(cpol_ctx *ctx, int n_vel, const double *varray);
 int cpol_set_quadrature(cpol_ctx *ctx, int n_sub, const double *az_off, const double *el_off,
                         const double *weight);
 
+/* Refraction scheme 2 (refraction/atm_refraction.py:45-84): the ray equation through the model's
+ * refractivity profile depends on the total elevation of a sub-beam only, so the host solves it once
+ * per distinct (ray elevation + vertical sub-beam offset) and passes the result here: n_profiles
+ * strictly ascending keys (degrees, exactly el + el_off in float64) and S, H, E as
+ * [n_profiles][n_gates] float32 in the reference's units.  Rays whose sub-beams find no key get
+ * CPOL_ERR_REFRACTION in ray_status.  n_profiles = 0 returns to the built-in 4/3 earth-radius
+ * model (atm_refraction.py:110-123), which is the default. */
+int cpol_set_refraction_table(cpol_ctx *ctx, int n_profiles, const double *elevation_keys, const float *S,
+                              const float *H, const float *E);
+
 /* ---- the hot path ------------------------------------------------------------------- */
 /* One call = what the pool workers of radar_operator.py:237-256 do for n_rays rays:
  * get_profiles_GH -> get_doppler_velocity -> get_radar_observables (+ cut_at_sensitivity
@@ -150,7 +161,7 @@ int cpol_set_quadrature(cpol_ctx *ctx, int n_sub, const double *az_off, const do
  *   rvel  float64 [n_rays][n_gates]               (doppler_scheme 1 or 2)
  *   mask  float64 [n_rays][n_gates]               scattering_sz.py:144-151
  *   lat, lon float64, dist, height float32 [n_rays][n_gates]   central sub-beam geometry
- * ray_status int32 [n_rays]: CPOL_OK or CPOL_ERR_DOMAIN per ray.
+ * ray_status int32 [n_rays]: CPOL_OK, CPOL_ERR_DOMAIN or CPOL_ERR_REFRACTION per ray.
  * cpol_run_rays copies to host buffers.  cpol_run_rays_dev works on device memory: members
  * of dev_out that are non-NULL on entry are caller-owned device buffers and are filled in
  * place; NULL members are served from ctx-owned buffers (valid until the next call) whose

@@ -778,13 +778,16 @@ def get_radar_beam_trilin(list_vars, azimuth, dist, heights, cfg):
     return lats, lons, beams
 
 
-def get_profiles_GH(dic_variables, azimuth, elevation, cfg):
-    """interpolation/interpolation.py:53-308, integration scheme 1, refraction scheme 1."""
+def get_profiles_GH(dic_variables, azimuth, elevation, cfg, list_refraction=0):
+    """interpolation/interpolation.py:53-308, integration scheme 1; refraction scheme 1 unless the caller
+    hands in list_refraction = [(S, H, E) per vertical node] as the reference's parameter of that name allows
+    (:247-258)."""
     keys = list(dic_variables.keys())
     list_vars = list(dic_variables.values())
     subs, pts_ver = gh_quadrature(cfg)
     rr = radar_ranges(cfg)
-    refr = [ref_4_3(rr, pt + elevation, cfg['radar']['coords']) for pt in pts_ver]
+    refr = list_refraction if list_refraction != 0 else \
+        [ref_4_3(rr, pt + elevation, cfg['radar']['coords']) for pt in pts_ver]
     out = []
     for (i, j, ph, pv, w) in subs:
         S, H, E = refr[j]

@@ -360,6 +360,44 @@ def gen_quadrature():
     save('quadrature', **out)
 
 
+class _OldIndexArray(np.ndarray):
+    """ndarray that accepts float indices the way NumPy < 1.12 did (truncation towards zero with a
+    deprecation warning): the reference indexes with np.round(...) results (atm_refraction.py:57,59)."""
+    def __getitem__(self, idx):
+        fix = lambda i: int(i) if isinstance(i, (float, np.floating)) else i
+        if isinstance(idx, tuple):
+            idx = tuple(fix(i) for i in idx)
+        else:
+            idx = fix(idx)
+        return np.asarray(super(_OldIndexArray, self).__getitem__(idx))
+
+
+def gen_refraction_ode():
+    """refraction/atm_refraction.py:45-84 (refraction scheme 2) run by the reference on a synthetic
+    refractivity field (rotated-pole position of the radar through the stand-in)."""
+    from oracle import cosmo_oracle as O
+    cfg, constants = ref_shim.install()
+    ref_shim.install_geo_standins()
+    from cosmo_pol.refraction import atm_refraction
+    m = syn.synthetic_model(nz=30, ny=60, nx=64, scheme=1, seed=5, llc=(-1.6, -1.5), res=(0.05, 0.05),
+                            pole=(-44.0, 8.5), ztop=20000.)
+    z = m['zlev'].astype(np.float64)
+    # refractivity with a surface duct: strong gradient in the lowest 400 m above the terrain
+    agl = z - z[-1][None]
+    Nf = (320. * np.exp(-z / 7500.) + 60. * np.exp(-agl / 150.)).astype('float32')
+    attrs = {'z-levels': m['zlev'].view(_OldIndexArray), 'proj_info': m['proj_info'], 'resolution': m['resolution']}
+    Nobj = O.ModelVar(Nf.view(_OldIndexArray), attrs)
+    coords = [46.0, 8.5, 1500.]
+    out = {'N': Nf, 'zlev': m['zlev'], 'coords': np.array(coords), 'proj_keys': np.array(list(m['proj_info'].keys())),
+           'proj_vals': np.array([float(v) for v in m['proj_info'].values()]), 'resolution': np.array(m['resolution'])}
+    for tag, rr in (('c', np.arange(250., 100000., 500.)), ('x', np.arange(37.5, 20000., 75.))):
+        out['rr_' + tag] = rr
+        for el in (0.3, 1.0, 5.0, 30.0):
+            S, H, E = atm_refraction.get_radar_refraction(rr, el, coords, 2, Nobj)
+            out['S_%s_%g' % (tag, el)], out['H_%s_%g' % (tag, el)], out['E_%s_%g' % (tag, el)] = S, H, E
+    save('refraction_ode', **out)
+
+
 def gen_lutpack():
     """lookup/lut.py: int16 packing (float_to_uint16 / get_float_data), lookup_pts, lookup_line on a small table."""
     ref_shim.install()
@@ -407,3 +445,4 @@ if __name__ == '__main__':
     gen_quadrature()
     gen_profiles()
     gen_lutpack()
+    gen_refraction_ode()

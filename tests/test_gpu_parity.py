@@ -556,3 +556,61 @@ def test_profiles_vs_reference_run(name, tmp_path):
         for v in ('T', 'QR_v', 'U'):
             util.assert_close(bm.values[v], g['%s_val_%s' % (name, v)][b], rtol=2e-5, atol=1e-12, name=v)
     assert n_ulp <= 0.002 * 3 * len(beams) * len(beams[0].dist_profile) + 1
+
+
+def _refractivity_field(m):
+    z = m['zlev'].astype(np.float64)
+    agl = z - z[-1][None]
+    return (320. * np.exp(-z / 7500.) + 60. * np.exp(-agl / 150.)).astype('float32')
+
+
+def test_refraction_scheme_2_table():
+    """refraction.scheme 2 (atm_refraction.py:45-84): profiles solved on the host (pinned against the reference by
+    the 'refraction_ode' golden), looked up on the GPU by total elevation; everything downstream against the
+    oracle fed the same profiles through the reference's list_refraction parameter (interpolation.py:247-258)."""
+    from cosmo_pol_amd import RadarOperator, refraction, cfg as pcfg, model as pmodel, runtime
+    from cosmo_pol_amd.constants import constants
+    conf = pipeline_conf(1, 3, 3)
+    conf['refraction'] = {'scheme': 2}
+    runtime.reset()
+    pcfg.set_config(conf)
+    constants.update()
+    m = pipeline_model(1)
+    fields = dict(m['fields'])
+    fields['N'] = _refractivity_field(m)
+    dic = pmodel.variables_from_arrays(fields, m['zlev'], m['proj_info'], m['resolution'])
+    op = RadarOperator(conf)
+    op.load_model_file(dic)
+    assert 'N' not in op.dic_vars and op.N != 0
+    op.set_lut(1, {h: Lookup_table.from_arrays(*t) for h, t in util.synthetic_lut_arrays(1, 5.6).items()})
+    els = [0.5, 4.0, 25.0]
+    radar = op.get_RHI(200.0, elevations=els)
+    olut = util.oracle_luts(1, 5.6)
+    rr = O.radar_ranges(conf)
+    subs, pts_ver = O.gh_quadrature(conf)
+    for i, el in enumerate(els):
+        refr = [refraction.ref_ODE_s(rr, pt + el, conf['radar']['coords'], op.N) for pt in pts_ver]
+        # the table differs from the 4/3 model, or the test would prove nothing
+        assert np.abs(refr[1][1] - O.ref_4_3(rr, pts_ver[1] + el, conf['radar']['coords'])[1]).max() > 1.0
+        with np.errstate(all='ignore'):
+            beams = O.get_profiles_GH(oracle_model_vars(m), 200.0, el, conf, list_refraction=refr)
+            want = O.get_radar_observables(beams, olut, conf)
+            want.values.update(O.get_doppler_velocity(beams, olut, conf).values)
+            O.cut_at_sensitivity([want], conf)
+        np.testing.assert_array_equal(radar.gate_altitude['data'][i], want.heights_profile)
+        zh = radar.fields['ZH']['data'][i].filled(np.nan)
+        wdb = 10 * np.log10(want.values['ZH'])
+        np.testing.assert_array_equal(np.isnan(zh), np.isnan(wdb))
+        ok = ~np.isnan(wdb)
+        assert np.abs(zh[ok] - wdb[ok]).max() < 0.01
+        util.assert_close(radar.fields['KDP']['data'][i].filled(np.nan), want.values['KDP'], rtol=1e-5,
+                          atol=1e-5 * np.nanmax(np.abs(want.values['KDP']), initial=0.), name='KDP')
+        util.assert_close(radar.fields['RVEL']['data'][i].filled(np.nan), want.values['RVEL'], rtol=1e-5, atol=1e-6,
+                          name='RVEL')
+    # a ray whose elevation has no profile is reported, not silently mis-refracted
+    st = runtime.get_engine(0, doppler=1, sensitivity_cut=True)
+    with pytest.raises(_lib.CosmoPolError):
+        st.eng.ctx.run_rays(np.array([200.0]), np.array([7.77]))
+    st.eng.set_refraction(None)
+    out = st.eng.ctx.run_rays(np.array([200.0]), np.array([7.77]))
+    assert (out['ray_status'] == 0).all()

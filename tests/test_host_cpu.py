@@ -250,3 +250,32 @@ def test_lut_file_roundtrip_and_frequency_interpolation(tmp_path):
     arr = read_lut.from_arrays_dir(str(d))
     assert list(arr) == ['R']
     np.testing.assert_array_equal(arr['R'].value_table, tab)
+
+
+# ---------------------------------------------------------------------------------------------
+# refraction on the host (refraction/atm_refraction.py)
+# ---------------------------------------------------------------------------------------------
+def test_ref_4_3_host_vs_reference():
+    from cosmo_pol_amd import refraction
+    g = np.load(os.path.join(GOLDEN, 'refraction.npz'))
+    for tag in ('lema', 'mxpol'):
+        for el in (-0.2, 1.0, 3.3, 20.0, 40.0, 90.0):
+            S, H, E = refraction.ref_4_3(g['rr_' + tag], el, list(g['coords']))
+            np.testing.assert_array_equal(S, g['S_%s_%g' % (tag, el)])
+            np.testing.assert_array_equal(H, g['H_%s_%g' % (tag, el)])
+            np.testing.assert_array_equal(E, g['E_%s_%g' % (tag, el)])
+
+
+def test_ref_ode_vs_reference():
+    """Refraction scheme 2 against the reference's run (LSODA both sides; float32 outputs)."""
+    from cosmo_pol_amd import refraction
+    from cosmo_pol_amd.model import ModelVariable
+    g = np.load(os.path.join(GOLDEN, 'refraction_ode.npz'))
+    proj = {str(k): float(v) for k, v in zip(g['proj_keys'], g['proj_vals'])}
+    N = ModelVariable('N', g['N'], {'z-levels': g['zlev'], 'proj_info': proj, 'resolution': list(g['resolution'])})
+    for tag in ('c', 'x'):
+        for el in (0.3, 1.0, 5.0, 30.0):
+            S, H, E = refraction.get_radar_refraction(g['rr_' + tag], el, list(g['coords']), 2, N)
+            np.testing.assert_allclose(S, g['S_%s_%g' % (tag, el)], rtol=2e-6, atol=1e-3)
+            np.testing.assert_allclose(H, g['H_%s_%g' % (tag, el)], rtol=2e-6, atol=1e-3)
+            np.testing.assert_allclose(E, g['E_%s_%g' % (tag, el)], rtol=2e-6, atol=1e-6)
