@@ -556,7 +556,8 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
                                  cpol_outputs *out)
 {
     TRY(check_ready(ctx, true, true));
-    if (n_rays < 1 || !azimuth || !elevation || !out) return CPOL_ERR_ARG;
+    if (n_rays == 0) return CPOL_OK;              // an empty scan is not an error
+    if (n_rays < 0 || !azimuth || !elevation || !out) return CPOL_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ClassTable ct;
     TRY(build_class_table(ctx, ct));
@@ -642,6 +643,7 @@ extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, c
     cpol_outputs d;
     memset(&d, 0, sizeof(d));
     TRY(cpol_run_rays_dev(ctx, n_rays, azimuth, elevation, &d));
+    if (n_rays == 0) return CPOL_OK;
     const size_t RG = (size_t)n_rays * ctx->cfg.n_gates;
     hipStream_t s = ctx->stream;
     if (host->obs) HIPCHK(ctx, hipMemcpyAsync(host->obs, d.obs, CPOL_N_OBS * RG * sizeof(float), hipMemcpyDeviceToHost, s));

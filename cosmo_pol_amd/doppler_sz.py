@@ -20,6 +20,14 @@ def get_doppler_velocity(list_beams, lut_sz=0, device=0):
     vals, elev, mask, w = _pack(list_beams, len_beams)
     az = np.array([b.GH_pt[0] for b in list_beams], dtype=np.float64)
     _, mask_out, rvel = st.eng.ctx.observables_from_beams(vals, elev, mask, w, az)
+    if any(len(b.mask) != len_beams for b in list_beams):
+        # sub-beams of unequal length (GPM): this function pads the masks with 0 where get_radar_observables pads
+        # with 1 (doppler_sz.py:110 against scattering_sz.py:146)
+        mask_out = np.zeros(len_beams)
+        for b in list_beams:
+            mask_out[:len(b.mask)] += b.mask
+        mask_out /= len(list_beams)
+        mask_out[np.logical_and(mask_out >= 0, mask_out < 1)] = 0
     c = list_beams[int(len(list_beams) / 2)]
     vals_out = {'RVEL': rvel}
     if scheme == 3:

@@ -345,7 +345,9 @@ def integrate_sz(list_beams, luts, cfg):
             valid = beam.values['Q' + h + '_v'] > 0
             elev = fold_elevation(beam.elev_profile)
             T = beam.values['T']
-            sz = lut.lookup_line(e=elev[valid], t=T[valid])
+            # a boolean index shorter than the array (sub-beam longer than the central one, GPM) selected from
+            # the leading part in the NumPy the reference was written for
+            sz = lut.lookup_line(e=elev[:len(valid)][valid], t=T[valid])
             QM = beam.values['Q' + h + '_v']
             if scheme == 1:
                 if h != 'S':

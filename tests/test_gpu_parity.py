@@ -614,3 +614,71 @@ def test_refraction_scheme_2_table():
     st.eng.set_refraction(None)
     out = st.eng.ctx.run_rays(np.array([200.0]), np.array([7.77]))
     assert (out['ray_status'] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------------
+def test_empty_scan():
+    conf = pipeline_conf(1, 1, 1)
+    m = pipeline_model(1)
+    eng = make_engine(conf)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    eng.set_gauss_hermite()
+    out = eng.ctx.run_rays(np.zeros(0), np.zeros(0))
+    assert out['obs'].shape == (9, 0, 40) and out['rvel'].shape == (0, 40)
+
+
+def test_out_of_table_temperatures_and_folded_elevations():
+    """T beyond both ends of the table axis clamps to the end nodes (lut.py:240-241), elevations above 90 and
+    below 0 fold back (scattering_sz.py:66-68); the unfolded angle still projects the wind (doppler_sz.py:76)."""
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': 2}, radar={'radial_resolution': 500., 'frequency': 5.6})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(64, 3, 1, seed=41, res=500.)
+    rng = np.random.default_rng(2)
+    for b in beams:
+        b['values']['T'][:] = rng.choice([150., 199.9, 230., 262., 275.5, 315., 350.], 64).astype('float32')
+        b['elev'][:] = rng.choice([-3.5, -0.2, 0., 1., 45., 89.9, 90., 90.1, 135., 179.], 64).astype('float32')
+        for k in ('QR_v', 'QS_v', 'QG_v'):
+            b['values'][k][:] = np.abs(b['values'][k]) + np.float32(1e-5)
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    luts = util.oracle_luts(1, 5.6)
+    with np.errstate(all='ignore'):
+        want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf)
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
+    check_obs(obs, want.values, 'clamp/fold')
+    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+
+
+def test_longer_subbeams_are_truncated_to_the_central_one():
+    """scattering_sz.py:54-57 (GPM: sub-beams longer than the central beam) through the Python API."""
+    from cosmo_pol_amd import scattering_sz, doppler_sz, cfg as pcfg, runtime
+    from cosmo_pol_amd.beam import Beam
+    from cosmo_pol_amd.constants import constants
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': 1}, radar={'radial_resolution': 500., 'frequency': 5.6})
+    runtime.reset()
+    pcfg.set_config(conf)
+    constants.update()
+    raw = syn.synthetic_beams(50, 3, 1, seed=8, res=500.)
+    lens = [50, 44, 47]          # the central beam (index 1) is the shortest
+
+    def cut(b, n):
+        return dict(values={k: v[:n].copy() for k, v in b['values'].items()}, mask=b['mask'][:n].copy(),
+                    elev=b['elev'][:n].copy(), dist=b['dist'][:n].copy(), heights=b['heights'][:n].copy(),
+                    GH_pt=b['GH_pt'], GH_weight=b['GH_weight'])
+    beams = [cut(b, n) for b, n in zip(raw, lens)]
+    luts = {h: Lookup_table.from_arrays(*t) for h, t in util.synthetic_lut_arrays(1, 5.6).items()}
+    mine = [Beam(dict(b['values']), b['mask'].copy(), None, None, b['dist'], b['heights'], b['elev'].copy(),
+                 list(b['GH_pt']), b['GH_weight']) for b in cut_all(beams)]
+    pol = scattering_sz.get_radar_observables(mine, luts)
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(cut_all(beams)), util.oracle_luts(1, 5.6), conf)
+    assert len(pol.values['ZH']) == 44
+    check_obs(np.stack([pol.values[n] for n in OBS]), want.values, 'ragged')
+    np.testing.assert_array_equal(pol.mask, want.mask)
+    assert all(len(v) == 44 for b in mine for v in b.values.values())        # visible truncation of the inputs
+
+
+def cut_all(beams):
+    import copy
+    return copy.deepcopy(beams)
