@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--doppler', type=int, choices=[0, 1, 2], default=2, help='doppler.scheme of the workload')
+    ap.add_argument('--batch-units', type=int, default=0, help='positions per internal batch (0 = library default)')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
     args = ap.parse_args()
 
@@ -146,6 +147,8 @@ def main():
     eng.set_gauss_hermite()
     del model
     ctx = eng.ctx
+    if args.batch_units:
+        ctx.set_batch_units(args.batch_units)
 
     if args.scaling == 'strong' and world > 1:
         n_az = len(np.unique(azs))

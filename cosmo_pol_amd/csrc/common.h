@@ -122,7 +122,7 @@ struct cpol_ctx {
     Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
         b_sorted, b_rank, b_psd, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
         o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
-    size_t max_batch_units = (size_t)8 << 20;     // (ray x sub-beam x gate) positions per batch
+    size_t max_batch_units = (size_t)16 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;

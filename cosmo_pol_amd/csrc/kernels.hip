@@ -352,7 +352,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     float dx = 1.0f - x, dy = 1.0f - y;
     int code = 0;          // 0 ok, 1 below terrain (NaN), -1 above the domain (-9999)
     int c1[4];
-    const int nz = mv.nz;
+    const int nz = mv.nz, nv = mv.nv;
     long cell[4];
     if (iy < 0 || ix < 0 || iy + 1 >= mv.ny || ix + 1 >= mv.nx || !(p0 == p0) || !(p1 == p1)) {
         code = 1;          // outside the grid: the reference raises before reaching the C code
@@ -415,7 +415,6 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
         }
     }
     if (mask && live) mask[u] = (signed char)code;
-    const int nv = mv.nv;
     s_code[wv][lane] = code;
     s_xy[wv][0][lane] = x; s_xy[wv][1][lane] = y; s_xy[wv][2][lane] = dx; s_xy[wv][3][lane] = dy;
 #pragma unroll
@@ -427,39 +426,45 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             float za = zc[0], zb = zc[1];
             fzj = za - zb;
             hzj = H - zb;
-            basej = (int)(cell[j] * nz + c1[j]);
+            basej = (int)((cell[j] * nz + c1[j]) * nv);       // element offset of the level pair (< 2^31)
         }
         s_base[wv][j][lane] = basej; s_fz[wv][j][lane] = fzj; s_hz[wv][j][lane] = hzj;
     }
     __syncthreads();
     {
-        const int sl = lane & 31, v = sl & 15, lev = sl >> 4;
+        // 32 lanes per point: lanes 0-15 take neighbour columns 0 and 1, lanes 16-31 columns 2 and 3; lane v of a
+        // half handles variable v.  A column's two levels are 2 nv contiguous floats, so every load instruction
+        // reads runs of nv consecutive floats.
+        const int sl = lane & 31, v = sl & 15, half = sl >> 4;
         const bool vact = v < nv;
+        const float *dlane = mv.dcol + v;
+        const int c0 = 2 * half, c1_ = 2 * half + 1;
         for (int p8 = 0; p8 < 32; p8 += 8) {
             // issue the 32 loads of eight point pairs before using any of them
-            float val[8][4];
+            float va[8][2], vb[8][2];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int pos = 2 * (p8 + i) + (lane >> 5);
-                const bool ok = s_code[wv][pos] == 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    val[i][j] = 0.f;
-                    if (ok && vact) val[i][j] = mv.dcol[(long)s_base[wv][j][pos] * nv + lev * nv + v];
-                }
+                const bool ok = s_code[wv][pos] == 0 && vact;
+                const int b0 = s_base[wv][c0][pos], b1 = s_base[wv][c1_][pos];
+                va[i][0] = ok ? dlane[b0] : 0.f; vb[i][0] = ok ? dlane[b0 + nv] : 0.f;
+                va[i][1] = ok ? dlane[b1] : 0.f; vb[i][1] = ok ? dlane[b1 + nv] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int pos = 2 * (p8 + i) + (lane >> 5);
-                float w[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    float vb = __shfl_down(val[i][j], 16);
-                    w[j] = vb - (vb - val[i][j]) / s_fz[wv][j][pos] * s_hz[wv][j][pos];
-                }
+                // vertical interpolation of the lane's two columns (interpolation_c.c:151)
+                const float w0 = vb[i][0] - (vb[i][0] - va[i][0]) / s_fz[wv][c0][pos] * s_hz[wv][c0][pos];
+                const float w1 = vb[i][1] - (vb[i][1] - va[i][1]) / s_fz[wv][c1_][pos] * s_hz[wv][c1_][pos];
                 const float px = s_xy[wv][0][pos], py = s_xy[wv][1][pos], pdx = s_xy[wv][2][pos], pdy = s_xy[wv][3][pos];
-                float o = pdx * pdy * w[0] + px * w[2] * pdy + pdx * w[1] * py + px * py * w[3];
-                if (lev == 0 && vact) s_out[wv][v][pos] = o;
+                // the four products of  dx*dy*v0 + x*v2*dy + dx*v1*y + x*y*v3  (:162), each in the reference's
+                // left-to-right order: columns 0, 1 in the lower half, columns 2, 3 in the upper half
+                const float ta = half ? (px * w0) * pdy : (pdx * pdy) * w0;      // t1 | t0
+                const float tb = half ? (px * py) * w1 : (pdx * w1) * py;        // t3 | t2
+                const int s1 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, ta), 0x401f);
+                const int s3 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, tb), 0x401f);
+                const float o = ((ta + __builtin_bit_cast(float, s1)) + tb) + __builtin_bit_cast(float, s3);
+                if (half == 0 && vact) s_out[wv][v][pos] = o;
             }
         }
     }
@@ -852,9 +857,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                  const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
-    constexpr int LDS_ZERO = SLICE_FLOATS;       // 4 zero floats read by the lanes of the spare columns
-    constexpr int LDS_X = SLICE_FLOATS + 4;
-    __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 4 + 1024];
+    constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
+    constexpr int LDS_X = SLICE_FLOATS + 64;
+    __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 64 + 1024];
 
     // XCD-aware chunk order: workgroups that share an XCD (blockIdx % 8) take consecutive
     // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2.
@@ -890,7 +895,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         for (int i = 0; i < SLICE_FLOATS / 4 / INTEG_THREADS; i++) dst[tid + i * INTEG_THREADS] = src[tid + i * INTEG_THREADS];
         static_assert(SLICE_FLOATS % (4 * INTEG_THREADS) == 0, "slice must be a whole number of 16-byte rounds");
         ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
-        if (tid == 0) *(float4 *)(lds + LDS_ZERO) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -901,7 +906,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
     // float4 index of this lane's operand word: quad q -> bbase + q * bstride; the lanes of the
     // four spare columns read a zero word
-    const int bbase = j < NC ? kq * NC + j : LDS_ZERO / 4;
+    // (the zero word of a 16-lane group sits in the banks its NC real words leave free)
+    const int bbase = j < NC ? kq * NC + j : (LDS_ZERO + ((kq * NC * 4 + NC * 4) & 63)) / 4;
     const int bstride = j < NC ? 4 * NC : 0;
 
     for (int g0 = wave * 2; g0 < ngroups; g0 += 8) {

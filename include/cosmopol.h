@@ -112,7 +112,7 @@ int cpol_timing_enable(cpol_ctx *ctx, int on);          /* also resets the total
 int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_launches[CPOL_N_STAGES],
                      double *valid_units, double *doppler_units);
 /* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
- * workspace the library allocates (default 8 Mi positions, about 3.5 GB). */
+ * workspace the library allocates (default 16 Mi positions, about 13 GB with 2-moment input and Doppler scheme 2). */
 int cpol_set_batch_units(cpol_ctx *ctx, long max_units);
 
 /* ---- state -------------------------------------------------------------------------- */
