@@ -695,11 +695,8 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
                 n0d[dslot] = n0 * exp2(-l2 * ct.dop_x0[h]);      // k_integrate_dop works relative to the first diameter
             }
             if (live) key[dslot] = kd;
-            wave_run(kd, lane, &hl, &len);
-            base = 0;
-            if (kd >= 0 && hl == lane) base = atomicAdd(&hist[kd * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))], len);
-            base = __shfl(base, hl);
-            if (kd >= 0) rank[dslot] = base + (lane - hl);
+            // the Doppler units of a bucket are as many as its polarimetric ones and take the same ranks:
+            // k_scan_shards and k_scatter reuse the polarimetric counters, no second round of atomics
         }
     }
     if (doppler == 1 && live) {
@@ -762,12 +759,13 @@ void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, cons
 // k_scan_shards (one thread per bucket) turns a bucket's counters into shard cursors relative to the
 // bucket start and leaves the bucket's unit and chunk counts in offs / chunk_off; k_scan_buckets (one
 // workgroup) scans those in place into bucket offsets and the chunk table of the integrate kernels.
-__global__ void k_scan_shards(int nb, const int *__restrict__ hist, int *__restrict__ offs, int *__restrict__ cursor,
-                              int *__restrict__ chunk_off)
+__global__ void k_scan_shards(int nb, int nb_counted, const int *__restrict__ hist, int *__restrict__ offs,
+                              int *__restrict__ cursor, int *__restrict__ chunk_off)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nb) return;
-    const int4 *h4 = (const int4 *)(hist + j * CPOL_SORT_SHARDS);
+    // buckets beyond nb_counted (separate Doppler units) mirror the counters of bucket j - nb_counted
+    const int4 *h4 = (const int4 *)(hist + (j < nb_counted ? j : j - nb_counted) * CPOL_SORT_SHARDS);
     int4 *c4 = (int4 *)(cursor + j * CPOL_SORT_SHARDS);
     int v = 0;
 #pragma unroll
@@ -810,28 +808,32 @@ __global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__
     if (t == 1023) { offs[nb] = s_a[1023]; chunk_off[nb] = s_b[1023]; }
 }
 
-void launch_scan(hipStream_t s, int nb, int *hist, int *offs, int *cursor, int *chunk_off)
+void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off)
 {
-    hipLaunchKernelGGL(k_scan_shards, dim3((nb + 255) / 256), dim3(256), 0, s, nb, hist, offs, cursor, chunk_off);
+    hipLaunchKernelGGL(k_scan_shards, dim3((nb + 255) / 256), dim3(256), 0, s, nb, nb_counted, hist, offs, cursor, chunk_off);
     hipLaunchKernelGGL(k_scan_buckets, dim3(1), dim3(1024), 0, s, nb, offs, chunk_off);
 }
 
 // Final position of every valid unit = bucket start + start of its shard inside the bucket + the rank
 // k_prep drew.
-__global__ void k_scatter(long nu, const int *__restrict__ key, const int *__restrict__ rank,
+__global__ void k_scatter(long nu, int n_ranked, const int *__restrict__ key, const int *__restrict__ rank,
                           const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
-    long slot = (long)blockIdx.y * nu + u;
+    const int pl = blockIdx.y;
+    long slot = (long)pl * nu + u;
     int k = key[slot];
-    if (k >= 0) sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
+    // planes beyond n_ranked (separate Doppler units) take the rank of their polarimetric twin
+    if (k >= 0) sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] +
+                       rank[(long)(pl < n_ranked ? pl : pl - n_ranked) * nu + u]] = (int)slot;
 }
 
-void launch_scatter(hipStream_t s, long nu, int n_planes, const int *key, const int *rank, const int *offs,
+void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, const int *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, key, rank, offs, cursor, sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, n_ranked, key, rank,
+                       offs, cursor, sorted);
 }
 
 // =============================================================================
