@@ -1022,24 +1022,36 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     double s12 = 0., s13 = 0.;
     const float gstep = ct.dop_geo_step[h];
     if (gstep > 0.f) {
-        // nu = 1 on a uniform axis: the four diameters of a word are 4 steps apart, so
-        // N = (n, n R, n R^2, n R^3) with R = exp(-lambda 4 step): one exponential per word
+        // nu = 1 on a uniform axis: N(D) is a geometric sequence.  The four diameters of a word are 4 steps
+        // apart (ratio R), the same word of the next quad is 16 steps further (ratio R^4): one exponential seeds
+        // four quads of one word position, i.e. 16 diameters; at most five roundings separate a value from its seed
         const float R = __builtin_amdgcn_exp2f(-(l.x * gstep + l.y * gstep));
-        const f32x2 R2 = {R * R, R * R};
-        for (int wo = 0; wo < 256; wo += 32) {
+        const float Rsq = R * R;
+        const f32x2 R2 = {Rsq, Rsq};
+        const f32x2 R4 = R2 * R2;
+        for (int qo = 0; qo < 64; qo += 8) {
             f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
-#pragma unroll 8
-            for (int w = wo; w < wo + 32; w++) {
-                const float x0 = lds[12 * w];
-                const float4 b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
-                const float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x0, -l.y * x0));
-                const f32x2 n01 = {n0, n0 * R};
-                const f32x2 n23 = n01 * R2;
-                const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
-                a12 = __builtin_elementwise_fma(n01, u01, a12);
-                a13 = __builtin_elementwise_fma(n01, v01, a13);
-                a12 = __builtin_elementwise_fma(n23, u23, a12);
-                a13 = __builtin_elementwise_fma(n23, v23, a13);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+#pragma unroll
+                for (int hq = 0; hq < 8; hq += 4) {
+                    const int w0 = 4 * (qo + hq) + k;
+                    const float x0 = lds[12 * w0];
+                    const float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x0, -l.y * x0));
+                    f32x2 n01 = {n0, n0 * R};
+                    f32x2 n23 = n01 * R2;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int w = w0 + 4 * m;
+                        const float4 b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
+                        const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
+                        a12 = __builtin_elementwise_fma(n01, u01, a12);
+                        a13 = __builtin_elementwise_fma(n01, v01, a13);
+                        a12 = __builtin_elementwise_fma(n23, u23, a12);
+                        a13 = __builtin_elementwise_fma(n23, v23, a13);
+                        if (m < 3) { n01 = n01 * R4; n23 = n23 * R4; }
+                    }
+                }
             }
             s12 += (double)a12.x + (double)a12.y;
             s13 += (double)a13.x + (double)a13.y;
