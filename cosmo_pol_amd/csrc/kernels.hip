@@ -983,7 +983,37 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
 // packed-f32 exponent and accumulate, float64 flush every 128 diameters like k_integrate.
 // Buckets [b_lo, b_hi) of the chunk table.
 // =============================================================================
-__global__ __launch_bounds__(CPOL_CHUNK_UNITS)
+#define DOP_THREADS (CPOL_CHUNK_UNITS / 2)      // two units per lane: every LDS word read serves both
+
+// plain path of one unit: one exponential per diameter
+__device__ inline void dop_unit_plain(const float *lds, float2 l, double *o12, double *o13)
+{
+    const float4 *I4 = (const float4 *)lds;
+    const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
+    double s12 = 0., s13 = 0.;
+    for (int wo = 0; wo < 256; wo += 32) {
+        f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
+#pragma unroll 4
+        for (int w = wo; w < wo + 32; w++) {
+            const float4 x = I4[3 * w], b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
+            const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
+            const f32x2 p01 = __builtin_elementwise_fma(nhi, x01, nlo * x01);
+            const f32x2 p23 = __builtin_elementwise_fma(nhi, x23, nlo * x23);
+            const f32x2 n01 = {__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
+            const f32x2 n23 = {__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
+            const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
+            a12 = __builtin_elementwise_fma(n01, u01, a12);
+            a13 = __builtin_elementwise_fma(n01, v01, a13);
+            a12 = __builtin_elementwise_fma(n23, u23, a12);
+            a13 = __builtin_elementwise_fma(n23, v23, a13);
+        }
+        s12 += (double)a12.x + (double)a12.y;
+        s13 += (double)a13.x + (double)a13.y;
+    }
+    *o12 = s12; *o13 = s13;
+}
+
+__global__ __launch_bounds__(DOP_THREADS)
 void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                      const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
 {
@@ -1012,90 +1042,96 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         const float4 *src = (const float4 *)(lv.table + (long)(ie * lv.n_t + it) * CPOL_DOP_SLICE);
         float4 *dst = (float4 *)lds;
 #pragma unroll
-        for (int i = 0; i < CPOL_DOP_SLICE / 4 / CPOL_CHUNK_UNITS; i++) dst[tid + i * CPOL_CHUNK_UNITS] = src[tid + i * CPOL_CHUNK_UNITS];
+        for (int i = 0; i < CPOL_DOP_SLICE / 4 / DOP_THREADS; i++) dst[tid + i * DOP_THREADS] = src[tid + i * DOP_THREADS];
     }
     __syncthreads();
-    if (tid >= cnt) return;
-    const int slot = sorted[start + tid];
-    const float2 l = lam[slot];
+    // units tid and tid + DOP_THREADS of the chunk
+    const bool have[2] = {tid < cnt, tid + DOP_THREADS < cnt};
+    if (!have[0]) return;
+    int slot[2];
+    float2 l[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        slot[t] = have[t] ? sorted[start + tid + t * DOP_THREADS] : 0;
+        l[t] = have[t] ? lam[slot[t]] : make_float2(0.f, 0.f);
+    }
     const float4 *I4 = (const float4 *)lds;
-    double s12 = 0., s13 = 0.;
+    double s12[2] = {0., 0.}, s13[2] = {0., 0.};
     const float gstep = ct.dop_geo_step[h];
     if (gstep > 0.f) {
         // nu = 1 on a uniform axis: N(D) is a geometric sequence.  The four diameters of a word are 4 steps
         // apart (ratio R), the same word of the next quad is 16 steps further (ratio R^4): one exponential seeds
         // four quads of one word position, i.e. 16 diameters; at most five roundings separate a value from its seed
-        const float R = __builtin_amdgcn_exp2f(-(l.x * gstep + l.y * gstep));
-        const float Rsq = R * R;
-        const f32x2 R2 = {Rsq, Rsq};
-        const f32x2 R4 = R2 * R2;
+        float R[2];
+        f32x2 R2[2], R4[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            R[t] = __builtin_amdgcn_exp2f(-(l[t].x * gstep + l[t].y * gstep));
+            const float rs = R[t] * R[t];
+            R2[t] = (f32x2){rs, rs};
+            R4[t] = R2[t] * R2[t];
+        }
         for (int qo = 0; qo < 64; qo += 8) {
-            f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
+            f32x2 a12[2] = {{0.f, 0.f}, {0.f, 0.f}}, a13[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
 #pragma unroll
                 for (int hq = 0; hq < 8; hq += 4) {
                     const int w0 = 4 * (qo + hq) + k;
                     const float x0 = lds[12 * w0];
-                    const float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x0, -l.y * x0));
-                    f32x2 n01 = {n0, n0 * R};
-                    f32x2 n23 = n01 * R2;
+                    f32x2 n01[2], n23[2];
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, x0, -l[t].y * x0));
+                        n01[t] = (f32x2){n0, n0 * R[t]};
+                        n23[t] = n01[t] * R2[t];
+                    }
 #pragma unroll
                     for (int m = 0; m < 4; m++) {
                         const int w = w0 + 4 * m;
                         const float4 b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
                         const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
-                        a12 = __builtin_elementwise_fma(n01, u01, a12);
-                        a13 = __builtin_elementwise_fma(n01, v01, a13);
-                        a12 = __builtin_elementwise_fma(n23, u23, a12);
-                        a13 = __builtin_elementwise_fma(n23, v23, a13);
-                        if (m < 3) { n01 = n01 * R4; n23 = n23 * R4; }
+#pragma unroll
+                        for (int t = 0; t < 2; t++) {
+                            a12[t] = __builtin_elementwise_fma(n01[t], u01, a12[t]);
+                            a13[t] = __builtin_elementwise_fma(n01[t], v01, a13[t]);
+                            a12[t] = __builtin_elementwise_fma(n23[t], u23, a12[t]);
+                            a13[t] = __builtin_elementwise_fma(n23[t], v23, a13[t]);
+                            if (m < 3) { n01[t] = n01[t] * R4[t]; n23[t] = n23[t] * R4[t]; }
+                        }
                     }
                 }
             }
-            s12 += (double)a12.x + (double)a12.y;
-            s13 += (double)a13.x + (double)a13.y;
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                s12[t] += (double)a12[t].x + (double)a12[t].y;
+                s13[t] += (double)a13[t].x + (double)a13[t].y;
+            }
         }
     } else {
-        const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
-        for (int wo = 0; wo < 256; wo += 32) {
-            f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
-#pragma unroll 4
-            for (int w = wo; w < wo + 32; w++) {
-                const float4 x = I4[3 * w], b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
-                const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
-                const f32x2 p01 = __builtin_elementwise_fma(nhi, x01, nlo * x01);
-                const f32x2 p23 = __builtin_elementwise_fma(nhi, x23, nlo * x23);
-                const f32x2 n01 = {__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
-                const f32x2 n23 = {__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
-                const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
-                a12 = __builtin_elementwise_fma(n01, u01, a12);
-                a13 = __builtin_elementwise_fma(n01, v01, a13);
-                a12 = __builtin_elementwise_fma(n23, u23, a12);
-                a13 = __builtin_elementwise_fma(n23, v23, a13);
-            }
-            s12 += (double)a12.x + (double)a12.y;
-            s13 += (double)a13.x + (double)a13.y;
-        }
+        for (int t = 0; t < 2; t++)
+            if (have[t]) dop_unit_plain(lds, l[t], &s12[t], &s13[t]);
     }
     // unit-spacing trapezoid rule (doppler_sz.py:219-220): the sum minus half of the two end terms
-    {
-        const int wl = 12 * 255 + 3;                 // d = 1023 is the last element of the last word
-        const float x0 = lds[0], xl = lds[wl];
-        const float na = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x0, -l.y * x0));
-        const float nz = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, xl, -l.y * xl));
-        s12 -= 0.5 * ((double)na * (double)lds[4] + (double)nz * (double)lds[wl + 4]);
-        s13 -= 0.5 * ((double)na * (double)lds[8] + (double)nz * (double)lds[wl + 8]);
+    const int wl = 12 * 255 + 3;                 // d = 1023 is the last element of the last word
+    const float x0 = lds[0], xl = lds[wl];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        if (!have[t]) continue;
+        const float na = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, x0, -l[t].y * x0));
+        const float nz = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, xl, -l[t].y * xl));
+        const double r12 = s12[t] - 0.5 * ((double)na * (double)lds[4] + (double)nz * (double)lds[wl + 4]);
+        const double r13 = s13[t] - 0.5 * ((double)na * (double)lds[8] + (double)nz * (double)lds[wl + 8]);
+        psd_out[(long)slot[t] * CPOL_N_COL + 12] = (float)r12;
+        psd_out[(long)slot[t] * CPOL_N_COL + 13] = (float)r13;
     }
-    psd_out[(long)slot * CPOL_N_COL + 12] = (float)s12;
-    psd_out[(long)slot * CPOL_N_COL + 13] = (float)s13;
 }
 
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out)
 {
     if (max_chunks <= 0) return;
-    hipLaunchKernelGGL(k_integrate_dop, dim3((unsigned)max_chunks), dim3(CPOL_CHUNK_UNITS), 0, s, ct, b_lo, b_hi, offs,
+    hipLaunchKernelGGL(k_integrate_dop, dim3((unsigned)max_chunks), dim3(DOP_THREADS), 0, s, ct, b_lo, b_hi, offs,
                        chunk_off, sorted, lam, psd_out);
 }
 
