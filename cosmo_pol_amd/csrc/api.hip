@@ -425,7 +425,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
     TRY(ensure(ctx, ctx->b_sorted, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_rank, nslots * sizeof(int)));
-    TRY(ensure(ctx, ctx->b_psd, (size_t)nslots * CPOL_N_COL * sizeof(float)));
+    TRY(ensure(ctx, ctx->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
+    if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
     TRY(ensure(ctx, ctx->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
     if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->b_n0d, nslots * sizeof(double)));
@@ -438,7 +439,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
                 (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
                 (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off);
-    launch_scatter(ctx->stream, nu, n_planes, ct.n_cls, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
+    launch_scatter(ctx->stream, nu, n_planes, ct.n_cls, nb_pol, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
                    (int *)ctx->b_sorted.p);
     }
     if (ctx->timing) {
@@ -465,7 +466,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
         launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->b_sorted.p,
-                             (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
+                             (const float2 *)ctx->b_lam.p, (float2 *)ctx->b_dop.p, (long)ct.n_cls * nu);
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
@@ -474,6 +475,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     if (ctx->cfg.doppler_scheme == 2) {
         d2.vals = vals; d2.plane = plane; d2.elev = elev; d2.phi_sc = phi;
         d2.lam = (const float2 *)ctx->b_lam.p; d2.n0d = (const double *)ctx->b_n0d.p;
+        d2.dop_out = (const float2 *)ctx->b_dop.p;
         d2.n_cls = ct.n_cls; d2.ne_max = ct.ne_max; d2.nt_max = ct.nt_max; d2.shared = ct.dop_shared;
         if (ct.dop_shared) {       // columns 12, 13 of the 14-column image; d = 1023 is (q, k, s) = (63, 3, 3)
             d2.slice_floats = 1024 * 14;

@@ -680,9 +680,7 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             // 2-moment variables): same table node, separate unit (kind 1)
             const PsdView &pd = ct.dop[h];
             const long dslot = (long)(ct.n_cls + h) * nu + u;
-            int kd = -1;
             if (valid) {
-                kd = k + ct.n_cls * ct.ne_max * ct.nt_max;
                 float qd = vals[(long)pd.q_var * plane + uu];
                 float qnd = pd.qn_var >= 0 ? vals[(long)pd.qn_var * plane + uu] : 0.f;
                 float Td = vals[(long)pd.t_var * plane + uu];
@@ -694,7 +692,6 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
                 lam[dslot] = make_float2(hi, (float)(l2 - (double)hi));
                 n0d[dslot] = n0 * exp2(-l2 * ct.dop_x0[h]);      // k_integrate_dop works relative to the first diameter
             }
-            if (live) key[dslot] = kd;
             // the Doppler units of a bucket are as many as its polarimetric ones and take the same ranks:
             // k_scan_shards and k_scatter reuse the polarimetric counters, no second round of atomics
         }
@@ -816,24 +813,27 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 
 // Final position of every valid unit = bucket start + start of its shard inside the bucket + the rank
 // k_prep drew.
-__global__ void k_scatter(long nu, int n_ranked, const int *__restrict__ key, const int *__restrict__ rank,
+__global__ void k_scatter(long nu, int n_ranked, int nb_ranked, const int *__restrict__ key, const int *__restrict__ rank,
                           const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
     const int pl = blockIdx.y;
-    long slot = (long)pl * nu + u;
-    int k = key[slot];
-    // planes beyond n_ranked (separate Doppler units) take the rank of their polarimetric twin
-    if (k >= 0) sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] +
-                       rank[(long)(pl < n_ranked ? pl : pl - n_ranked) * nu + u]] = (int)slot;
+    // planes beyond n_ranked (separate Doppler units) have the key of their polarimetric twin moved up by the
+    // number of polarimetric buckets, and the twin's rank
+    const long twin = (long)(pl < n_ranked ? pl : pl - n_ranked) * nu + u;
+    int k = key[twin];
+    if (k < 0) return;
+    if (pl >= n_ranked) k += nb_ranked;
+    sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[twin]] =
+        (int)((long)pl * nu + u);
 }
 
-void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, const int *key, const int *rank, const int *offs,
-                    const int *cursor, int *sorted)
+void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, int nb_ranked, const int *key, const int *rank,
+                    const int *offs, const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, n_ranked, key, rank,
-                       offs, cursor, sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, n_ranked, nb_ranked,
+                       key, rank, offs, cursor, sorted);
 }
 
 // =============================================================================
@@ -1015,7 +1015,8 @@ __device__ inline void dop_unit_plain(const float *lds, float2 l, double *o12, d
 
 __global__ __launch_bounds__(DOP_THREADS)
 void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                     const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
+                     const int *__restrict__ sorted, const float2 *__restrict__ lam, float2 *__restrict__ dop_out,
+                     long slot0)
 {
     __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
     const int c_lo = chunk_off[b_lo];
@@ -1122,17 +1123,16 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         const float nz = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, xl, -l[t].y * xl));
         const double r12 = s12[t] - 0.5 * ((double)na * (double)lds[4] + (double)nz * (double)lds[wl + 4]);
         const double r13 = s13[t] - 0.5 * ((double)na * (double)lds[8] + (double)nz * (double)lds[wl + 8]);
-        psd_out[(long)slot[t] * CPOL_N_COL + 12] = (float)r12;
-        psd_out[(long)slot[t] * CPOL_N_COL + 13] = (float)r13;
+        dop_out[(long)slot[t] - slot0] = make_float2((float)r12, (float)r13);     // indexed like the polarimetric twin
     }
 }
 
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
-                          const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out)
+                          const int *chunk_off, const int *sorted, const float2 *lam, float2 *dop_out, long slot0)
 {
     if (max_chunks <= 0) return;
     hipLaunchKernelGGL(k_integrate_dop, dim3((unsigned)max_chunks), dim3(DOP_THREADS), 0, s, ct, b_lo, b_hi, offs,
-                       chunk_off, sorted, lam, psd_out);
+                       chunk_off, sorted, lam, dop_out, slot0);
 }
 
 // =============================================================================
@@ -1161,11 +1161,14 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
     double vh = 0., nn = 0.;
     bool any = false;
     for (int h = 0; h < d2.n_cls; h++) {
-        const long slot = (long)(d2.shared ? h : d2.n_cls + h) * nu + u;
-        int k = key[slot];
+        const long pslot = (long)h * nu + u;                            // polarimetric unit of the class
+        const long slot = d2.shared ? pslot : pslot + (long)d2.n_cls * nu;      // unit carrying the Doppler PSD
+        int k = key[pslot];
         if (k < 0) continue;
         any = true;
-        double s12 = (double)psd_out[slot * CPOL_N_COL + 12], s13 = (double)psd_out[slot * CPOL_N_COL + 13];
+        double s12, s13;
+        if (d2.shared) { s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13]; }
+        else { const float2 t = d2.dop_out[pslot]; s12 = (double)t.x; s13 = (double)t.y; }
         if (d2.shared) {
             // the MFMA columns hold plain sums: take half of the end terms off (unit-spacing trapezoid rule)
             const int it = k % d2.nt_max, ie = (k / d2.nt_max) % d2.ne_max;
