@@ -470,6 +470,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
+    op.row = ct.ncol == 12 ? 12 : CPOL_N_COL;
     Dop2In d2;
     memset(&d2, 0, sizeof(d2));
     if (ctx->cfg.doppler_scheme == 2) {

@@ -89,6 +89,7 @@ struct ObsParams {
     float  res, res_km;            // radial resolution and resolution / 1000 as float32 operands
     float  two_pi, zfac, kdpfac, two_wl, afac;
     int    att_corr, doppler, sens_mode;
+    int    row;                    // floats per result row of the PSD integration (12, or 16 with Doppler columns)
     double sens0, sens1, res_d;
 };
 

@@ -956,8 +956,10 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             for (int r = 0; r < 4; r++) {
                 int row = kq * 4 + r;
                 int u0 = g0 * 16 + row, u1 = u0 + 16;
-                if (u0 < cnt) psd_out[(long)sorted[start + u0] * CPOL_N_COL + j] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)sorted[start + u1] * CPOL_N_COL + j] = (float)db[r];
+                // result rows of 12 floats, 16 when the two Doppler moments ride along
+                constexpr int ROW = NC == 12 ? 12 : CPOL_N_COL;
+                if (u0 < cnt) psd_out[(long)sorted[start + u0] * ROW + j] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)sorted[start + u1] * ROW + j] = (float)db[r];
             }
         }
     }
@@ -1219,7 +1221,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
             long slot = (long)h * nu + u;
             if (key[slot] < 0) continue;
             double c = coef[slot];
-            const float4 *p = (const float4 *)(psd_out + slot * CPOL_N_COL);
+            const float4 *p = (const float4 *)(psd_out + slot * op.row);
             float4 v0 = p[0], v1 = p[1], v2 = p[2];
             const float vv[CPOL_N_SZ] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
