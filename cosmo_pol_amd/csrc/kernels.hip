@@ -364,45 +364,44 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
         float topo = dx * dy * t0 + x * t2 * dy + dx * t1 * y + x * y * t3;
         if (!(topo < H)) code = 1;
         else {
-            // the four column searches of interpolation_c.c:108-135 run in lockstep (same probes and
-            // decisions per column as the reference's loop; four loads in flight instead of one)
+            // The level search of interpolation_c.c:108-135 on a strictly descending column returns the last
+            // level that is not below H (an exact hit on a level returns that level, a hit on the lowest one
+            // the level above it), i.e. (number of levels >= H) - 1 capped at nz - 2; "above the top" and "below
+            // the lowest level" are decided first, as there.  The count comes from a fixed-length, branch-free
+            // bisection, the four columns in lockstep.
             const float *col[4];
-            int hi_[4], lo_[4], res[4];
-            bool done[4];
+            int res[4];
             bool above = false;
+            bool below[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 col[j] = mv.zcol + cell[j] * nz;
                 float top = col[j][0];
                 float bot = (j == 0) ? t0 : (j == 1) ? t1 : (j == 2) ? t2 : t3;   // col[j][nz-1]
-                hi_[j] = 0; lo_[j] = nz - 1; res[j] = 0; done[j] = false;
-                if (H > top) { above = true; done[j] = true; }
-                else if (H < bot) { res[j] = -2; done[j] = true; }
+                above = above || (H > top);
+                below[j] = H < bot;
+                res[j] = 0;
             }
             if (above) code = -1;
             else {
-                for (int itn = 0; itn < 32; itn++) {
-                    bool all = true;
+                int cnt[4] = {0, 0, 0, 0};
+                for (int step = 1 << (31 - __clz(nz)); step > 0; step >>= 1) {
                     float v[4];
-                    int mid[4];
+                    bool in[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        mid[j] = (hi_[j] + lo_[j]) / 2;
-                        if (!done[j] && !(hi_[j] < lo_[j])) { res[j] = hi_[j]; done[j] = true; }
-                        v[j] = done[j] ? 0.f : col[j][mid[j]];
+                        in[j] = cnt[j] + step <= nz;
+                        v[j] = col[j][in[j] ? cnt[j] + step - 1 : 0];
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (!done[j]) {
-                            if (v[j] == H) { res[j] = mid[j]; done[j] = true; }
-                            else if (lo_[j] == mid[j] || hi_[j] == mid[j]) { res[j] = hi_[j]; done[j] = true; }
-                            else if (v[j] < H) lo_[j] = mid[j];
-                            else if (v[j] > H) hi_[j] = mid[j];
-                            else { res[j] = hi_[j]; done[j] = true; }   // NaN height
-                        }
-                        all = all && done[j];
-                    }
-                    if (all) break;
+                    for (int j = 0; j < 4; j++)
+                        if (in[j] && v[j] >= H) cnt[j] += step;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int r = cnt[j] - 1;
+                    if (r > nz - 2) r = nz - 2;
+                    res[j] = below[j] ? -2 : r;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
