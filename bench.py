@@ -38,7 +38,7 @@ FLOP_PER_UNIT = 27 * N_D          # 12 components x (mul + add) + 3 for N(D), pe
 FLOP_PER_UNIT_DOP2 = 6 * N_D      # Doppler scheme 2: two more columns (N rcs, N v rcs), mul + add + weight each
 
 
-def workload_config(small=False, doppler=2):
+def workload_config(small=False, doppler=2, microphysics=2):
     from cosmo_pol_amd import cfg
     # Monte Lema's position; the altitude is 80 m above the synthetic terrain at that grid cell (a radar below
     # the terrain would see NaN air density at its first gate, which the reference turns into NaN RVEL for
@@ -48,7 +48,7 @@ def workload_config(small=False, doppler=2):
                       'sensitivity': [-15, 10000], '3dB_beamwidth': 1.},
             'integration': {'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.},
             'refraction': {'scheme': 1}, 'attenuation': {'correction': 1}, 'doppler': {'scheme': doppler},
-            'microphysics': {'scheme': 2}}
+            'microphysics': {'scheme': microphysics}}
     if small:
         conf['radar']['range'] = 50000
     cfg.set_config(conf)
@@ -114,6 +114,8 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--doppler', type=int, choices=[0, 1, 2], default=2, help='doppler.scheme of the workload')
+    ap.add_argument('--microphysics', type=int, choices=[1, 2], default=2,
+                    help='2 = the headline 2-moment workload; 1 = the same volume with 1-moment input (3 classes)')
     ap.add_argument('--batch-units', type=int, default=0, help='positions per internal batch (0 = library default)')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
     args = ap.parse_args()
@@ -123,12 +125,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
     from cosmo_pol_amd import synthetic as syn
-    conf = workload_config(args.small, args.doppler)
+    conf = workload_config(args.small, args.doppler, args.microphysics)
     azs, elv = volume_rays(args.small)
     shape = (80, 774, 1158) if not args.small else (24, 200, 240)
-    model = syn.synthetic_model(*shape, scheme=2, seed=20161111 + (rank if args.scaling == 'weak' else 0),
+    model = syn.synthetic_model(*shape, scheme=args.microphysics, seed=20161111 + (rank if args.scaling == 'weak' else 0),
                                 res=(0.01, 0.01) if not args.small else (0.05, 0.05))
-    tabs = {h: syn.synthetic_lut(h, 5.6) for h in syn.hydrom_types(2)}
+    tabs = {h: syn.synthetic_lut(h, 5.6) for h in syn.hydrom_types(args.microphysics)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -229,10 +231,11 @@ def main():
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'CH_PPI_lema volume: 20 elevations x 360 azimuths x %d gates, COSMO-1 grid '
-                                   '%dx%dx%d, 2-moment (4 classes), 3x3 Gauss-Hermite (9 sub-beams), attenuation on, '
-                                   'Doppler scheme %d%s' % (G, shape[2], shape[1], shape[0], args.doppler,
+                                   '%dx%dx%d, %d-moment (%d classes), 3x3 Gauss-Hermite (9 sub-beams), attenuation on, '
+                                   'Doppler scheme %d%s' % (G, shape[2], shape[1], shape[0], args.microphysics,
+                                                            args.microphysics + 2, args.doppler,
                                                             ' [SMALL DEBUG RUN - INVALID]' if args.small else ''),
-                       'rays_per_rank': R, 'gates': G, 'sub_beams': eng.ctx.n_sub, 'classes': 4,
+                       'rays_per_rank': R, 'gates': G, 'sub_beams': eng.ctx.n_sub, 'classes': args.microphysics + 2,
                        'parallelism': 'rays sharded, %d rank(s)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'k_integrate', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,

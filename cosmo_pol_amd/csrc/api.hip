@@ -370,6 +370,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
         // exponential per four diameters
         ct.dop_x0[h] = (double)(float)pow((double)L.d0, L.psd_dop.nu);
+        ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         fill_psd(ct.psd[h], L.psd);
         fill_psd(ct.dop[h], L.psd_dop);

@@ -58,7 +58,8 @@ struct ClassTable {
     LutView lut[CPOL_MAX_CLASSES];
     LutView lut_dop[CPOL_MAX_CLASSES];
     double  dop_x0[CPOL_MAX_CLASSES];         // D_0^nu of the Doppler PSD as float32 (separate Doppler units)
-    float   dop_geo_step[CPOL_MAX_CLASSES];   // 4 x diameter step when the Doppler PSD has nu = 1 on a uniform axis, else 0
+    float   dop_geo_step[CPOL_MAX_CLASSES];
+    float   pol_geo_step[CPOL_MAX_CLASSES];   // same for the polarimetric PSD   // 4 x diameter step when the Doppler PSD has nu = 1 on a uniform axis, else 0
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
 };
