@@ -428,6 +428,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->b_rank, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
+    TRY(ensure(ctx, ctx->b_cbkt, (size_t)((nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb + 1) * sizeof(int)));
     TRY(ensure(ctx, ctx->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
     if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->b_n0d, nslots * sizeof(double)));
@@ -439,7 +440,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
                 (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
                 (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
-    launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off);
+    launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->b_cbkt.p);
     launch_scatter(ctx->stream, nu, n_planes, ct.n_cls, nb_pol, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
                    (int *)ctx->b_sorted.p);
     }
@@ -461,12 +462,12 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const long max_chunks = (nu * ct.n_cls + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb_pol;
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
-    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_sorted.p,
+    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
                      (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
-        launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->b_sorted.p,
+        launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
                              (const float2 *)ctx->b_lam.p, (float2 *)ctx->b_dop.p, (long)ct.n_cls * nu);
     }
     ObsParams op;

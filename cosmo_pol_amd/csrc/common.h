@@ -122,7 +122,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     std::vector<Buf *> bufs;
     Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-        b_sorted, b_rank, b_psd, b_dop, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+        b_sorted, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
         o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)16 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
@@ -162,13 +162,15 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
                         int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
                         double beta_d);
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
-void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off);
+void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
+                 int *chunk_bucket);
 void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, int nb_ranked, const int *key, const int *rank,
                     const int *offs, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out);
+                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
-                          const int *chunk_off, const int *sorted, const float2 *lam, float2 *dop_out, long slot0);
+                          const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
+                          float2 *dop_out, long slot0);
 void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                             double mu_d, double nu_d, double alpha_d, double beta_d);
 struct SpecParams {

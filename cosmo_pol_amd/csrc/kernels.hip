@@ -804,10 +804,20 @@ __global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__
     if (t == 1023) { offs[nb] = s_a[1023]; chunk_off[nb] = s_b[1023]; }
 }
 
-void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off)
+// Bucket of every chunk, so that an integrate workgroup finds its bucket with one load instead of a
+// bisection of dependent loads: one wavefront per bucket writes its id over the bucket's chunk range.
+__global__ void k_fill_chunks(int nb, const int *__restrict__ chunk_off, int *__restrict__ chunk_bucket)
+{
+    const int j = blockIdx.x;
+    for (int c = chunk_off[j] + threadIdx.x; c < chunk_off[j + 1]; c += blockDim.x) chunk_bucket[c] = j;
+}
+
+void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
+                 int *chunk_bucket)
 {
     hipLaunchKernelGGL(k_scan_shards, dim3((nb + 255) / 256), dim3(256), 0, s, nb, nb_counted, hist, offs, cursor, chunk_off);
     hipLaunchKernelGGL(k_scan_buckets, dim3(1), dim3(1024), 0, s, nb, offs, chunk_off);
+    hipLaunchKernelGGL(k_fill_chunks, dim3(nb), dim3(64), 0, s, nb, chunk_off, chunk_bucket);
 }
 
 // Final position of every valid unit = bucket start + start of its shard inside the bucket + the rank
@@ -855,7 +865,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                 const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
+                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
@@ -870,13 +880,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const unsigned q8 = total / 8, r8 = total % 8, xcd = orig % 8;
     const unsigned cid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
 
-    // bucket of this chunk: last b with chunk_off[b] <= cid (empty buckets share their
-    // successor's offset, so the last one is the owner)
-    int lo = 0, hi = nb;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (chunk_off[mid] <= (int)cid) lo = mid; else hi = mid;
-    }
+    const int lo = chunk_bucket[cid];               // bucket of this chunk (k_fill_chunks)
     const int bkt = lo;
     const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
     int cnt = offs[bkt + 1] - start;
@@ -1005,15 +1009,15 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 }
 
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *sorted, const float2 *lam, float *psd_out)
+                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out)
 {
     if (max_chunks <= 0) return;
     if (ct.ncol == 12)
         hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           sorted, lam, psd_out);
+                           chunk_bucket, sorted, lam, psd_out);
     else
         hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           sorted, lam, psd_out);
+                           chunk_bucket, sorted, lam, psd_out);
 }
 
 // =============================================================================
@@ -1056,7 +1060,7 @@ __device__ inline void dop_unit_plain(const float *lds, float2 l, double *o12, d
 
 __global__ __launch_bounds__(DOP_THREADS)
 void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                     const int *__restrict__ sorted, const float2 *__restrict__ lam, float2 *__restrict__ dop_out,
+                     const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float2 *__restrict__ dop_out,
                      long slot0)
 {
     __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
@@ -1066,11 +1070,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     if (orig >= total) return;
     const unsigned q8 = total / 8, r8 = total % 8, xcd = orig % 8;
     const int cid = c_lo + (int)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8);
-    int lo = b_lo, hi = b_hi;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (chunk_off[mid] <= cid) lo = mid; else hi = mid;
-    }
+    const int lo = chunk_bucket[cid];               // bucket of this chunk (k_fill_chunks)
     const int bkt = lo;
     const int start = offs[bkt] + (cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
     int cnt = offs[bkt + 1] - start;
@@ -1169,11 +1169,11 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 }
 
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
-                          const int *chunk_off, const int *sorted, const float2 *lam, float2 *dop_out, long slot0)
+                          const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float2 *dop_out, long slot0)
 {
     if (max_chunks <= 0) return;
     hipLaunchKernelGGL(k_integrate_dop, dim3((unsigned)max_chunks), dim3(DOP_THREADS), 0, s, ct, b_lo, b_hi, offs,
-                       chunk_off, sorted, lam, dop_out, slot0);
+                       chunk_off, chunk_bucket, sorted, lam, dop_out, slot0);
 }
 
 // =============================================================================
