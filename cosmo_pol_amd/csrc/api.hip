@@ -126,23 +126,24 @@ extern "C" int cpol_create(int device, cpol_ctx **out)
 extern "C" int cpol_destroy(cpol_ctx *ctx)
 {
     if (!ctx) return CPOL_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    for (auto *b : ctx->bufs) if (b->p) hipFree(b->p);
-    if (ctx->zcol) hipFree(ctx->zcol);
-    if (ctx->dcol) hipFree(ctx->dcol);
-    if (ctx->quad_dev) hipFree(ctx->quad_dev);
-    if (ctx->varray_dev) hipFree(ctx->varray_dev);
-    if (ctx->refr_keys) hipFree(ctx->refr_keys);
-    if (ctx->refr_tab) hipFree(ctx->refr_tab);
-    if (ctx->rawptr_dev) hipFree((void *)ctx->rawptr_dev);
+    // teardown: nothing useful can be done about a failing free, so the statuses are dropped on purpose
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto *b : ctx->bufs) if (b->p) (void)hipFree(b->p);
+    if (ctx->zcol) (void)hipFree(ctx->zcol);
+    if (ctx->dcol) (void)hipFree(ctx->dcol);
+    if (ctx->quad_dev) (void)hipFree(ctx->quad_dev);
+    if (ctx->varray_dev) (void)hipFree(ctx->varray_dev);
+    if (ctx->refr_keys) (void)hipFree(ctx->refr_keys);
+    if (ctx->refr_tab) (void)hipFree(ctx->refr_tab);
+    if (ctx->rawptr_dev) (void)hipFree((void *)ctx->rawptr_dev);
     for (auto &l : ctx->lut) {
         float *owned[] = {l.raw, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
-        for (float *q : owned) if (q) hipFree(q);
+        for (float *q : owned) if (q) (void)hipFree(q);
     }
-    for (auto e : ctx->ev_pool) hipEventDestroy(e);
-    if (ctx->valid_host) hipHostFree(ctx->valid_host);
-    hipStreamDestroy(ctx->stream);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->valid_host) (void)hipHostFree(ctx->valid_host);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CPOL_OK;
 }
@@ -814,7 +815,8 @@ extern "C" float *get_refl(float *refl, int len, float *Da, int len_D_bins_x, in
     cpol_ctx *ctx = global_ctx();
     (void)o2; (void)o3; (void)o4; (void)o6; (void)o8; (void)o9; (void)o10; (void)o11; (void)o12; (void)o13; (void)o14; (void)o15;
     if (!ctx || len < len_D_bins_x) return nullptr;
-    hipSetDevice(ctx->device);
+    hipError_t err = hipSetDevice(ctx->device);
+    auto keep = [&err](hipError_t r) { if (err == hipSuccess) err = r; };      // first failure wins
     hipStream_t s = ctx->stream;
     const int nb = len_D_bins_x, nd = o5;
     size_t fb = sizeof(float);
@@ -822,16 +824,16 @@ extern "C" float *get_refl(float *refl, int len, float *Da, int len_D_bins_x, in
     if (ensure(ctx, ctx->t_a, total * fb) != CPOL_OK) return nullptr;
     float *d_refl = (float *)ctx->t_a.p, *d_Da = d_refl + len, *d_Db = d_Da + nb * 3, *d_D = d_Db + nb * 3,
           *d_rcs = d_D + nd * 3, *d_par = d_rcs + nd * 3;
-    hipMemsetAsync(d_refl, 0, len * fb, s);
-    hipMemcpyAsync(d_Da, Da, nb * 3 * fb, hipMemcpyDefault, s);
-    hipMemcpyAsync(d_Db, Db, nb * 3 * fb, hipMemcpyDefault, s);
-    hipMemcpyAsync(d_D, D, nd * 3 * fb, hipMemcpyDefault, s);
-    hipMemcpyAsync(d_rcs, rcs, nd * 3 * fb, hipMemcpyDefault, s);
+    keep(hipMemsetAsync(d_refl, 0, len * fb, s));
+    keep(hipMemcpyAsync(d_Da, Da, nb * 3 * fb, hipMemcpyDefault, s));
+    keep(hipMemcpyAsync(d_Db, Db, nb * 3 * fb, hipMemcpyDefault, s));
+    keep(hipMemcpyAsync(d_D, D, nd * 3 * fb, hipMemcpyDefault, s));
+    keep(hipMemcpyAsync(d_rcs, rcs, nd * 3 * fb, hipMemcpyDefault, s));
     const float *par[6] = {N0, mu, lambda, nu, step_D, Dmin};
-    for (int i = 0; i < 6; i++) hipMemcpyAsync(d_par + 3 * i, par[i], 3 * fb, hipMemcpyDefault, s);
+    for (int i = 0; i < 6; i++) keep(hipMemcpyAsync(d_par + 3 * i, par[i], 3 * fb, hipMemcpyDefault, s));
     if (nb > 0)
         launch_get_refl(s, d_refl, nb, d_Da, d_Db, d_D, d_rcs, d_par, d_par + 3, d_par + 6, d_par + 9, d_par + 12, d_par + 15);
-    hipMemcpyAsync(refl, d_refl, len * fb, hipMemcpyDefault, s);
-    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
-    return refl;
+    keep(hipMemcpyAsync(refl, d_refl, len * fb, hipMemcpyDefault, s));
+    keep(hipStreamSynchronize(s));
+    return err == hipSuccess ? refl : nullptr;
 }

@@ -631,7 +631,7 @@ __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
 }
 
 __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
-                       const float *__restrict__ elev, const signed char *__restrict__ mask,
+                       const float *__restrict__ elev, const signed char *__restrict__ /*mask: invalid gates carry NaN*/,
                        const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
                        int *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
                        double *__restrict__ coef, double *__restrict__ n0d, int *__restrict__ hist,
@@ -806,7 +806,7 @@ __global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__
 
 // Bucket of every chunk, so that an integrate workgroup finds its bucket with one load instead of a
 // bisection of dependent loads: one wavefront per bucket writes its id over the bucket's chunk range.
-__global__ void k_fill_chunks(int nb, const int *__restrict__ chunk_off, int *__restrict__ chunk_bucket)
+__global__ void k_fill_chunks(const int *__restrict__ chunk_off, int *__restrict__ chunk_bucket)
 {
     const int j = blockIdx.x;
     for (int c = chunk_off[j] + threadIdx.x; c < chunk_off[j + 1]; c += blockDim.x) chunk_bucket[c] = j;
@@ -817,7 +817,7 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 {
     hipLaunchKernelGGL(k_scan_shards, dim3((nb + 255) / 256), dim3(256), 0, s, nb, nb_counted, hist, offs, cursor, chunk_off);
     hipLaunchKernelGGL(k_scan_buckets, dim3(1), dim3(1024), 0, s, nb, offs, chunk_off);
-    hipLaunchKernelGGL(k_fill_chunks, dim3(nb), dim3(64), 0, s, nb, chunk_off, chunk_bucket);
+    hipLaunchKernelGGL(k_fill_chunks, dim3(nb), dim3(64), 0, s, chunk_off, chunk_bucket);
 }
 
 // Final position of every valid unit = bucket start + start of its shard inside the bucket + the rank
@@ -1313,7 +1313,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
 
 // Stage 2, one wavefront per ray: PHIDP and the attenuation as prefix scans along range, sensitivity cut.
 __global__ __launch_bounds__(64)
-void k_ray_scan(ObsParams op, int n_rays, float *__restrict__ obs, long obs_plane, long ray0,
+void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0,
                 double *__restrict__ rvel_out, double *__restrict__ spectrum, int n_vel)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
@@ -1381,7 +1381,7 @@ void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu,
     const long n = (long)n_rays * op.n_gates;
     hipLaunchKernelGGL(k_gate_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, n_rays, nu, key, coef,
                        psd_out, mask, weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
-    hipLaunchKernelGGL(k_ray_scan, dim3(n_rays), dim3(64), 0, s, op, n_rays, obs, obs_plane, ray0, rvel_out, spectrum,
+    hipLaunchKernelGGL(k_ray_scan, dim3(n_rays), dim3(64), 0, s, op, obs, obs_plane, ray0, rvel_out, spectrum,
                        n_vel);
 }
 
@@ -1452,7 +1452,7 @@ void launch_get_refl(hipStream_t s, float *refl, int nbins, const float *Da, con
 // graupel), as the reference's get_refl hard-wires.
 // =============================================================================
 __global__ __launch_bounds__(64)
-void k_spectrum(ClassTable ct, SpecParams sp, long nu_, const float *__restrict__ vals, long plane,
+void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float *__restrict__ vals, long plane,
                 const float *__restrict__ elev, const signed char *__restrict__ mask, const double *__restrict__ wsub,
                 const double *__restrict__ phi_sc, const double *__restrict__ varray,
                 const float *const *__restrict__ raw, const float *const *__restrict__ d_axis,
