@@ -460,6 +460,7 @@ def gh_quadrature(cfg):
 # ----------------------------------------------------------------------------
 # Doppler  (doppler/doppler_sz.py)
 # ----------------------------------------------------------------------------
+_trapz = getattr(np, 'trapezoid', None) or np.trapz      # same function, renamed in NumPy 2
 DEG2RAD = np.pi / 180.0
 
 
@@ -519,8 +520,8 @@ def get_v_hydro_weighted(beam, hydros, luts, cfg):
         if len(N.shape) == 1:
             N = np.reshape(N, [len(N), 1])
         v_f = hydros[h].get_V(list_D)
-        vh_w = np.trapz(N * v_f[:, np.newaxis] * rcs, axis=0)
-        n_w = np.trapz(N * rcs, axis=0)
+        vh_w = _trapz(N * v_f[:, np.newaxis] * rcs, axis=0)
+        n_w = _trapz(N * rcs, axis=0)
         vh_avg[valid] = nansum_arr(vh_avg[valid], vh_w)
         n_avg[valid] = nansum_arr(n_avg[valid], n_w)
     with np.errstate(invalid='ignore', divide='ignore'):
