@@ -119,3 +119,23 @@ def test_sampled_rays_vs_oracle(volume):
         util.assert_close(out['rvel'][r], want.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL %d' % r)
         np.testing.assert_array_equal(out['dist'][r], want.dist_profile)
         np.testing.assert_array_equal(out['height'][r], want.heights_profile)
+
+
+def test_bench_line_contract(capsys, monkeypatch):
+    """bench.py prints one JSON line carrying the fields the measurement contract names (reduced grid, run
+    in-process; the CPU baseline forks a worker pool and is left to the real bench run)."""
+    import json
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--small', '--steps', '1', '--warmup', '1', '--no-cpu-baseline'])
+    monkeypatch.delenv('RANK', raising=False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    bench.main()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'gates/s' and d['n_gpus'] == 1 and d['vs_baseline'] is None and d['dtype'] == 'f32'
+    assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-12
+    assert d['value'] > 0 and d['steps'] == 1 and d['warmup'] == 1
