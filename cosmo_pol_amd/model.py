@@ -29,3 +29,45 @@ def load_npz(path):
     proj = {str(k): float(v) for k, v in zip(z['proj_keys'], z['proj_vals'])}
     fields = {str(n): z['var_' + str(n)] for n in z['names']}
     return variables_from_arrays(fields, z['zlev'], proj, list(z['resolution']), time=z['time'].item())
+
+
+# ---------------------------------------------------------------------------------------------------
+# derived variables the operator works on (radar_operator.py:32-33: 'QR_v', 'QS_v', ..., 'RHO'; 'N' for
+# refraction scheme 2).  The reference gets them from pycosmo, which is not part of its repository; these are
+# the standard thermodynamic definitions and are not pinned against it.
+# ---------------------------------------------------------------------------------------------------
+R_DRY = 287.05          # J kg-1 K-1
+R_VAPOUR = 461.51
+
+MASS_SPECIES = ('QR', 'QS', 'QG', 'QH')
+NUMBER_SPECIES = ('QNR', 'QNS', 'QNG', 'QNH')
+
+
+def air_density(P, T, QV, condensate=0.):
+    """Density of moist air [kg m-3] from pressure [Pa], temperature [K], specific humidity and the specific
+    content of all condensate [kg kg-1]."""
+    return P / (R_DRY * T * (1. + (R_VAPOUR / R_DRY - 1.) * QV - condensate))
+
+
+def refractivity(P, T, QV):
+    """Radio refractivity N = (n - 1) 1e6 (Smith-Weintraub): 77.6 / T (p + 4810 e / T), pressures in hPa."""
+    e = QV * P / (0.622 + 0.378 * QV)
+    return 77.6 / T * (P / 100. + 4810. * (e / 100.) / T)
+
+
+def derive_variables(raw, with_refractivity=False):
+    """raw: {name: [nz, ny, nx]} with the model's prognostic fields (P, T, QV, U, V, W, QR, QS, QG and optionally
+    QC, QI, QH, QNR, QNS, QNG, QNH as mass / number per kg of air).  Returns the fields the operator interpolates:
+    U, V, W, T, RHO and the contents per volume of air Q*_v = Q* RHO, QN*_v = QN* RHO [, N]."""
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    P, T, QV = (np.asarray(raw[k], dtype=np.float64) for k in ('P', 'T', 'QV'))
+    cond = sum(np.asarray(raw[k], dtype=np.float64) for k in ('QC', 'QI') + MASS_SPECIES if k in raw)
+    rho = air_density(P, T, QV, cond)
+    out = {k: f32(raw[k]) for k in ('U', 'V', 'W', 'T')}
+    out['RHO'] = f32(rho)
+    for k in MASS_SPECIES + NUMBER_SPECIES:
+        if k in raw:
+            out[k + '_v'] = f32(np.asarray(raw[k], dtype=np.float64) * rho)
+    if with_refractivity:
+        out['N'] = f32(refractivity(P, T, QV))
+    return out

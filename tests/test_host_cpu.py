@@ -279,3 +279,19 @@ def test_ref_ode_vs_reference():
             np.testing.assert_allclose(S, g['S_%s_%g' % (tag, el)], rtol=2e-6, atol=1e-3)
             np.testing.assert_allclose(H, g['H_%s_%g' % (tag, el)], rtol=2e-6, atol=1e-3)
             np.testing.assert_allclose(E, g['E_%s_%g' % (tag, el)], rtol=2e-6, atol=1e-6)
+
+
+def test_derived_model_variables():
+    from cosmo_pol_amd import model
+    shp = (3, 4, 5)
+    raw = {'P': np.full(shp, 101325.), 'T': np.full(shp, 288.15), 'QV': np.zeros(shp), 'U': np.ones(shp), 'V': np.ones(shp),
+           'W': np.zeros(shp), 'QR': np.full(shp, 1e-3), 'QS': np.zeros(shp), 'QG': np.zeros(shp), 'QNR': np.full(shp, 1e4)}
+    out = model.derive_variables(raw, with_refractivity=True)
+    assert abs(out['RHO'][0, 0, 0] - 101325. / (287.05 * 288.15 * (1 - 1e-3))) < 1e-6          # dry air + rain loading
+    np.testing.assert_allclose(out['QR_v'], 1e-3 * out['RHO'], rtol=1e-6)
+    np.testing.assert_allclose(out['QNR_v'], 1e4 * out['RHO'], rtol=1e-6)
+    assert 'QH_v' not in out and out['T'].dtype == np.float32
+    assert abs(out['N'][0, 0, 0] - 77.6 / 288.15 * 1013.25) < 1e-3                              # dry term only
+    raw['QV'] = np.full(shp, 0.01)
+    wet = model.derive_variables(raw, with_refractivity=True)
+    assert wet['N'][0, 0, 0] > out['N'][0, 0, 0] + 40 and wet['RHO'][0, 0, 0] < out['RHO'][0, 0, 0]
