@@ -219,8 +219,14 @@ def main():
         # the two Doppler scheme-2 columns count for k_integrate only when they ride on its units; with
         # 2-moment input they are units of their own on the vector ALUs (stage integrate_dop)
         flop_unit = FLOP_PER_UNIT + (FLOP_PER_UNIT_DOP2 if args.doppler == 2 and tim['doppler_units'] == 0 else 0)
-        flop_per_launch = flop_unit * tim['valid_units'] / max(1, tim['launches']['integrate'])
+        # Of a unit's 1024 terms only those whose float32 N(D) is not an exact zero are evaluated (the library
+        # counts them); `achieved` prices the evaluated terms against the matrix-core peak, `algorithmic` is the
+        # rate of the reference's full 1024-term contraction that the same launch stands for.
+        evaluated = tim['evaluated_unit_diameters'] / (1024. * tim['valid_units']) if tim['valid_units'] else 1.
+        flop_alg_launch = flop_unit * tim['valid_units'] / max(1, tim['launches']['integrate'])
+        flop_per_launch = flop_alg_launch * evaluated
         achieved = flop_per_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
+        algorithmic = flop_alg_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath) and not args.small:
@@ -240,7 +246,8 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'k_integrate', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
-                         'launches': tim['launches']['integrate']},
+                         'launches': tim['launches']['integrate'], 'evaluated_fraction': evaluated,
+                         'algorithmic_tflops': algorithmic},
             'stage_ms_per_step': {k: v / args.steps for k, v in tim['ms'].items()},
             'valid_units_per_step': tim['valid_units'] / args.steps,
             'doppler_units_per_step': tim['doppler_units'] / args.steps,

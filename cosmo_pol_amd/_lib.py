@@ -55,7 +55,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -81,6 +81,7 @@ def load():
     lib.cpol_synchronize.argtypes = [vp]
     lib.cpol_timing_enable.argtypes = [vp, C.c_int]
     lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
+    lib.cpol_timing_work.argtypes = [vp, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
@@ -173,8 +174,10 @@ class Context(object):
         nl = (C.c_long * len(self.STAGES))()
         vu, du = C.c_double(), C.c_double()
         self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu), C.byref(du)), 'cpol_timing_read')
+        wk = C.c_double()
+        self._check(self.lib.cpol_timing_work(self.h, C.byref(wk)), 'cpol_timing_work')
         return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
-                'valid_units': vu.value, 'doppler_units': du.value}
+                'valid_units': vu.value, 'doppler_units': du.value, 'evaluated_unit_diameters': wk.value}
 
     def set_batch_units(self, n):
         self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')

@@ -73,6 +73,8 @@ extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     timing_collect(ctx);
+    if (on && !ctx->work_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->work_dev, 64 * sizeof(unsigned long long)));
+    if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, 64 * sizeof(unsigned long long)));
     ctx->timing = on != 0;
     for (int i = 0; i < CPOL_N_STAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_launches[i] = 0; }
     ctx->valid_units = 0; ctx->dop_units = 0;
@@ -92,6 +94,21 @@ extern "C" int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], l
     }
     if (valid_units) *valid_units = ctx->valid_units;
     if (doppler_units) *doppler_units = ctx->dop_units;
+    return CPOL_OK;
+}
+
+extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters)
+{
+    if (!ctx || !evaluated_unit_diameters) return CPOL_ERR_ARG;
+    *evaluated_unit_diameters = 0.;
+    if (!ctx->work_dev) return CPOL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long w[64];
+    HIPCHK(ctx, hipMemcpy(w, ctx->work_dev, sizeof(w), hipMemcpyDeviceToHost));
+    double tot = 0.;
+    for (int i = 0; i < 64; i++) tot += (double)w[i];
+    *evaluated_unit_diameters = 16. * tot;
     return CPOL_OK;
 }
 
@@ -134,6 +151,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->dcol) (void)hipFree(ctx->dcol);
     if (ctx->quad_dev) (void)hipFree(ctx->quad_dev);
     if (ctx->varray_dev) (void)hipFree(ctx->varray_dev);
+    if (ctx->work_dev) (void)hipFree(ctx->work_dev);
     if (ctx->refr_keys) (void)hipFree(ctx->refr_keys);
     if (ctx->refr_tab) (void)hipFree(ctx->refr_tab);
     if (ctx->rawptr_dev) (void)hipFree((void *)ctx->rawptr_dev);
@@ -257,6 +275,7 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
         L.axis_step = st;
         L.d0 = dax[0];
     }
+    L.d_host = dax;
     L.psd = *psd;
     L.psd_dop = psd_doppler ? *psd_doppler : *psd;
     L.present = true;
@@ -371,6 +390,10 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
         // exponential per four diameters
         ct.dop_x0[h] = (double)(float)pow((double)L.d0, L.psd_dop.nu);
+        // N(D) = 0 in float32 beyond a unit's cutoff needs D^nu ascending along the axis
+        bool asc = L.psd.nu > 0. && L.d_host.size() == 1024 && L.d_host[0] > 0.f;
+        for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
+        ct.cut_ok[h] = asc ? 1 : 0;
         ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         fill_psd(ct.psd[h], L.psd);
@@ -464,7 +487,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
     launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
-                     (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p);
+                     (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p, ctx->timing ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);

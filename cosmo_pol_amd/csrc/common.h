@@ -26,6 +26,7 @@ struct LutDev {
     bool   axis_uniform = false;   // diameters equally spaced to float32 rounding
     double axis_step = 0;
     float  d0 = 0;                 // first diameter
+    std::vector<float> d_host;     // the diameter axis as uploaded
     int    image_ncol = 0;         // what `table` was last built for
     bool   image_dop = false;
     cpol_psd psd, psd_dop;
@@ -62,6 +63,7 @@ struct ClassTable {
     float   pol_geo_step[CPOL_MAX_CLASSES];   // same for the polarimetric PSD   // 4 x diameter step when the Doppler PSD has nu = 1 on a uniform axis, else 0
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
+    int     cut_ok[CPOL_MAX_CLASSES];          // D^nu ascending along the diameter axis
 };
 
 struct ModelView {
@@ -126,6 +128,7 @@ struct cpol_ctx {
         o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)16 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
+    unsigned long long *work_dev = nullptr;       // 64 partial counts of unit x 16-diameter steps k_integrate evaluated (timing only)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -167,7 +170,8 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, int nb_ranked, const int *key, const int *rank,
                     const int *offs, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out);
+                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
+                      unsigned long long *work);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
                           float2 *dop_out, long slot0);

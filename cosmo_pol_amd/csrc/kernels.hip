@@ -616,6 +616,14 @@ __device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, 
     return true;
 }
 
+// D^nu beyond which exp2(-l2 * D^nu) is an exact float32 zero (the exponent passes -150 even after the
+// roundings of the quotient and of the product): terms past it add nothing to a float32 sum.  +inf (no
+// cutoff) for a lambda that is not a positive finite number, so that its NaN / inf results are kept.
+__device__ inline float psd_cutoff_x(float l2)
+{
+    return (l2 > 0.f && l2 < __builtin_inff()) ? 152.f / l2 : __builtin_inff();
+}
+
 // Position of the run of equal keys this lane belongs to inside its wave.
 __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
 {
@@ -856,6 +864,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define INTEG_THREADS 256
+#define INTEG_XCD_RUN 16         // consecutive chunks per XCD before the next XCD's run
 
 // Table image (global and LDS alike, built by k_build_image):
 //   img[((q*4*NC + k*NC + j) * 4 + s] = B'[d][j]   with d = 16 q + 4 s + k
@@ -865,20 +874,28 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out)
+                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out,
+                 unsigned long long *__restrict__ work)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
     constexpr int LDS_X = SLICE_FLOATS + 64;
+    static_assert(CPOL_CHUNK_UNITS == INTEG_THREADS, "the chunk-local sort handles one unit per thread");
     __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 64 + 1024];
+    // chunk-local counting sort of the units by the number of quads (16 diameters) their N(D) survives
+    // (its 65 counters borrow the start of the table area, which is filled only afterwards: with them in a
+    // region of their own the workgroup would pass the LDS size at which three fit a CU)
+    int *s_hist = (int *)lds;
+    __shared__ unsigned char s_perm[CPOL_CHUNK_UNITS];      // unit (index in the chunk) at each sorted position
 
-    // XCD-aware chunk order: workgroups that share an XCD (blockIdx % 8) take consecutive
-    // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2.
+    // XCD-aware chunk order: the workgroups of one XCD (blockIdx % 8) take runs of INTEG_XCD_RUN consecutive
+    // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2; the runs go round the XCDs
+    // because a chunk's cost depends on its class and node (cutoffs), and a contiguous eighth of the chunk
+    // list per XCD would leave some XCDs with all the expensive ones.
     const unsigned total = (unsigned)chunk_off[nb];
-    const unsigned orig = blockIdx.x;
-    if (orig >= total) return;
-    const unsigned q8 = total / 8, r8 = total % 8, xcd = orig % 8;
-    const unsigned cid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+    const unsigned xcd = blockIdx.x % 8, kx = blockIdx.x / 8;
+    const unsigned cid = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
+    if (cid >= total) return;
 
     const int lo = chunk_bucket[cid];               // bucket of this chunk (k_fill_chunks)
     const int bkt = lo;
@@ -891,22 +908,64 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int hk = bkt / (ct.nt_max * ct.ne_max);          // kind * n_cls + class
     const LutView lv = hk < ct.n_cls ? ct.lut[hk] : ct.lut_dop[hk - ct.n_cls];
     const float gstep = hk < ct.n_cls ? ct.pol_geo_step[hk] : 0.f;     // 4 x diameter step when N(D) is geometric
+    const bool cut_ok = hk < ct.n_cls && ct.cut_ok[hk];                // D^nu ascending: N(D) = 0 past a unit's cutoff
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
 
-    // ---- stage the slice: straight 16-byte copy of the pre-permuted image ----
+    // ---- D^nu first: it decides how much of the slice the chunk needs ----
+    ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
+    if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 68) s_hist[tid] = 0;
+    float2 lu = make_float2(0.f, 0.f);
+    if (tid < cnt) lu = lam[sorted[start + tid]];
+    __syncthreads();
+
+    // ---- order the chunk's units by where their N(D) becomes an exact float32 zero ----
+    // nqu = number of quads whose first D^nu does not exceed the unit's cutoff (bisection over 64 ascending values)
+    int nqu = 64;
+    if (cut_ok) {
+        const float xc = psd_cutoff_x(lu.x + lu.y);
+        nqu = 0;
+#pragma unroll
+        for (int step = 64; step >= 1; step >>= 1)
+            if (nqu + step <= 64 && lds[LDS_X + (nqu + step - 1) * 16] <= xc) nqu += step;
+    }
+    int myrank = 0;
+    if (tid < cnt) myrank = atomicAdd(&s_hist[nqu], 1);
+    __syncthreads();
+    if (wave == 0) {
+        const int h = s_hist[lane];
+        int incl = h;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { int o = __shfl_up(incl, m); if (lane >= m) incl += o; }
+        const int n64 = s_hist[64];
+        s_hist[lane] = incl - h;
+        if (lane == 63) s_hist[64] = incl;
+        // largest cutoff of the chunk = highest bin in use
+        const unsigned long long used = __ballot(h > 0);
+        if (lane == 0) s_hist[65] = n64 > 0 ? 64 : 63 - __clzll(used);
+    }
+    __syncthreads();
+    const int nq_chunk = s_hist[65];
+    if (tid < cnt) s_perm[s_hist[nqu] + myrank] = (unsigned char)tid;
+    __syncthreads();
+
+    // ---- stage the quads the chunk needs: straight 16-byte copy of the pre-permuted image ----
     {
         const float4 *src = (const float4 *)(lv.table + (long)(ie * lv.n_t + it) * SLICE_FLOATS);
         float4 *dst = (float4 *)lds;
-#pragma unroll
-        for (int i = 0; i < SLICE_FLOATS / 4 / INTEG_THREADS; i++) dst[tid + i * INTEG_THREADS] = src[tid + i * INTEG_THREADS];
+        // a quad is 16 * NC floats; the geometric path evaluates whole seed groups of four quads
+        const int n4 = ((nq_chunk + 3) & ~3) * 4 * NC;
+        constexpr int PER = SLICE_FLOATS / 4 / INTEG_THREADS;
         static_assert(SLICE_FLOATS % (4 * INTEG_THREADS) == 0, "slice must be a whole number of 16-byte rounds");
-        ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
-        if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; i++) if (tid + i * INTEG_THREADS < n4) v[i] = src[tid + i * INTEG_THREADS];
+#pragma unroll
+        for (int i = 0; i < PER; i++) if (tid + i * INTEG_THREADS < n4) dst[tid + i * INTEG_THREADS] = v[i];
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
-    const int ngroups = (cnt + 15) >> 4;
     const int kq = lane >> 4, j = lane & 15;
     const float4 *B4 = (const float4 *)lds;
     const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
@@ -915,80 +974,121 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     // (the zero word of a 16-lane group sits in the banks its NC real words leave free)
     const int bbase = j < NC ? kq * NC + j : (LDS_ZERO + ((kq * NC * 4 + NC * 4) & 63)) / 4;
     const int bstride = j < NC ? 4 * NC : 0;
+    const int npass = (cnt + 31) >> 5;
+    unsigned wsum = 0;
 
-    for (int g0 = wave * 2; g0 < ngroups; g0 += 8) {
+    // passes of 32 units in cutoff order; the four waves take them in snake order (0 1 2 3 3 2 1 0 ...) so
+    // that every wave gets cheap and expensive ones
+    for (int r4 = 0; r4 * 4 < npass; r4++) {
+        const int ps = r4 * 4 + ((r4 & 1) ? 3 - wave : wave);
+        if (ps >= npass) continue;
+        const int g0 = ps * 2;
         // two groups of 16 units per pass: two independent accumulators, and the two units'
         // exponent arguments are formed together with packed f32 arithmetic
         int ua = g0 * 16 + j, ub = ua + 16;
         // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
         float2 la = make_float2(0.f, 0.f), lb = la;
-        if (ua < cnt) la = lam[sorted[start + ua]];
-        if (ub < cnt) lb = lam[sorted[start + ub]];
+        if (ua < cnt) la = lam[sorted[start + s_perm[ua]]];
+        if (ub < cnt) lb = lam[sorted[start + s_perm[ub]]];
         const f32x2 nhi = {-la.x, -lb.x}, nlo = {-la.y, -lb.y};
         double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+        // quads up to the last one in which any of the pass's units still has a nonzero float32 N(D): the count
+        // of its last unit in cutoff order (lane 15's second unit, or the chunk's last)
+        int nq = 64;
+        if (cut_ok) {
+            const int ulast = min(g0 * 16 + 31, cnt - 1);
+            const float2 ll = ulast >= g0 * 16 + 16 ? lb : la;
+            const float xc = __shfl(psd_cutoff_x(ll.x + ll.y), ulast & 15);
+            nq = 0;
+#pragma unroll
+            for (int step = 64; step >= 1; step >>= 1)
+                if (nq + step <= 64 && lds[LDS_X + (nq + step - 1) * 16] <= xc) nq += step;
+        }
+        wsum += (unsigned)nq * (unsigned)min(cnt - g0 * 16, 32);
         if (gstep > 0.f) {
             // nu = 1 on a uniform diameter axis: N(D) is a geometric sequence.  A lane's four values of a quad
             // are 4 diameters apart (ratio R per unit), the same lane's values of the next quad 16 further
             // (ratio R^4): one exponential per unit seeds four quads, the rest are packed multiplications (at
-            // most five roundings from the seed)
+            // most five roundings from the seed).  Seed groups are evaluated whole: one that is skipped starts
+            // beyond every cutoff, so its seed is an exact zero.
             const f32x2 arg = {la.x * gstep + la.y * gstep, lb.x * gstep + lb.y * gstep};
             const f32x2 Rv = {__builtin_amdgcn_exp2f(-arg.x), __builtin_amdgcn_exp2f(-arg.y)};
             const f32x2 R2v = Rv * Rv;
             const f32x2 R4v = R2v * R2v;
-            for (int qo = 0; qo < 64; qo += 8) {
-                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-                for (int q0 = qo; q0 < qo + 8; q0 += 4) {
-                    const float x0 = X4[q0 * 4].x;
-                    const f32x2 x2 = {x0, x0};
-                    const f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);
-                    f32x2 n0 = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
-                    f32x2 n1 = n0 * Rv, n2 = n0 * R2v;
-                    f32x2 n3 = n1 * R2v;
+            // one seed group: quads q0 .. q0+3
+            auto seed_group = [&](int q0, f32x4 &acca, f32x4 &accb) {
+                const float x0 = X4[q0 * 4].x;
+                const f32x2 x2 = {x0, x0};
+                const f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);
+                f32x2 n0 = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+                f32x2 n1 = n0 * Rv, n2 = n0 * R2v;
+                f32x2 n3 = n1 * R2v;
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const float4 bq = B4[bbase + (q0 + m) * bstride];
-                        __builtin_amdgcn_sched_barrier(0);
-                        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n0.x, bq.x, acca, 0, 0, 0);
-                        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n0.y, bq.x, accb, 0, 0, 0);
-                        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n1.x, bq.y, acca, 0, 0, 0);
-                        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n1.y, bq.y, accb, 0, 0, 0);
-                        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n2.x, bq.z, acca, 0, 0, 0);
-                        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n2.y, bq.z, accb, 0, 0, 0);
-                        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n3.x, bq.w, acca, 0, 0, 0);
-                        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n3.y, bq.w, accb, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (m < 3) { n0 = n0 * R4v; n1 = n1 * R4v; n2 = n2 * R4v; n3 = n3 * R4v; }
-                    }
+                for (int m = 0; m < 4; m++) {
+                    const float4 bq = B4[bbase + (q0 + m) * bstride];
+                    __builtin_amdgcn_sched_barrier(0);
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n0.x, bq.x, acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n0.y, bq.x, accb, 0, 0, 0);
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n1.x, bq.y, acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n1.y, bq.y, accb, 0, 0, 0);
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n2.x, bq.z, acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n2.y, bq.z, accb, 0, 0, 0);
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n3.x, bq.w, acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n3.y, bq.w, accb, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m < 3) { n0 = n0 * R4v; n1 = n1 * R4v; n2 = n2 * R4v; n3 = n3 * R4v; }
                 }
+            };
+            const int nq4 = (nq + 3) & ~3;
+            // float64 flush every 128 diameters (two seed groups), whatever the pass's length
+            for (int qo = 0; qo + 8 <= nq4; qo += 8) {
+                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+                seed_group(qo, acca, accb);
+                seed_group(qo + 4, acca, accb);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
+            }
+            if (nq4 & 4) {
+                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+                seed_group(nq4 - 4, acca, accb);
 #pragma unroll
                 for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
             }
         } else {
-            for (int qo = 0; qo < 64; qo += 8) {
-                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-                for (int qd = qo; qd < qo + 8; qd++) {
-                    float4 bq = B4[bbase + qd * bstride];
-                    float4 xq = X4[qd * 4];
-                    const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-                    const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
-                    // all eight N(D) values of the quad first (independent registers), then the
-                    // eight MFMAs back to back: no MFMA waits for a transcendental result
-                    float na[4], nb_[4];
+            auto quad = [&](int qd, f32x4 &acca, f32x4 &accb) {
+                float4 bq = B4[bbase + qd * bstride];
+                float4 xq = X4[qd * 4];
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+                const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
+                // all eight N(D) values of the quad first (independent registers), then the
+                // eight MFMAs back to back: no MFMA waits for a transcendental result
+                float na[4], nb_[4];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) {
-                        const f32x2 x2 = {xx[s4], xx[s4]};
-                        f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);   // one rounding of -(hi+lo)*x
-                        na[s4] = __builtin_amdgcn_exp2f(p.x);
-                        nb_[s4] = __builtin_amdgcn_exp2f(p.y);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) {
-                        acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na[s4], bb[s4], acca, 0, 0, 0);
-                        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_[s4], bb[s4], accb, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const f32x2 x2 = {xx[s4], xx[s4]};
+                    f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);   // one rounding of -(hi+lo)*x
+                    na[s4] = __builtin_amdgcn_exp2f(p.x);
+                    nb_[s4] = __builtin_amdgcn_exp2f(p.y);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na[s4], bb[s4], acca, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_[s4], bb[s4], accb, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // float64 flush every 128 diameters (8 quads), whatever the pass's length
+            for (int qo = 0; qo + 8 <= nq; qo += 8) {
+                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 8; t++) quad(qo + t, acca, accb);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
+            }
+            if (nq & 7) {
+                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+                for (int qd = nq & ~7; qd < nq; qd++) quad(qd, acca, accb);
 #pragma unroll
                 for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
             }
@@ -1001,23 +1101,28 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 int u0 = g0 * 16 + row, u1 = u0 + 16;
                 // result rows of 12 floats, 16 when the two Doppler moments ride along
                 constexpr int ROW = NC == 12 ? 12 : CPOL_N_COL;
-                if (u0 < cnt) psd_out[(long)sorted[start + u0] * ROW + j] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)sorted[start + u1] * ROW + j] = (float)db[r];
+                if (u0 < cnt) psd_out[(long)sorted[start + s_perm[u0]] * ROW + j] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)sorted[start + s_perm[u1]] * ROW + j] = (float)db[r];
             }
         }
+    }
+    if (work) {                                       // wave-uniform count of evaluated unit x quad steps
+        if (lane == 0) atomicAdd(&work[(blockIdx.x * 4 + wave) & 63], (unsigned long long)wsum);
     }
 }
 
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out)
+                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
+                      unsigned long long *work)
 {
     if (max_chunks <= 0) return;
+    max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
     if (ct.ncol == 12)
         hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, lam, psd_out);
+                           chunk_bucket, sorted, lam, psd_out, work);
     else
         hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, lam, psd_out);
+                           chunk_bucket, sorted, lam, psd_out, work);
 }
 
 // =============================================================================
