@@ -389,11 +389,12 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
         // exponential per four diameters
+        ct.pol_x0[h] = pow((double)L.d0, L.psd.nu);
         ct.dop_x0[h] = (double)(float)pow((double)L.d0, L.psd_dop.nu);
         // N(D) = 0 in float32 beyond a unit's cutoff needs D^nu ascending along the axis
-        bool asc = L.psd.nu > 0. && L.d_host.size() == 1024 && L.d_host[0] > 0.f;
+        bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
         for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
-        ct.cut_ok[h] = asc ? 1 : 0;
+        ct.cut_ok[h] = (asc && L.psd.nu > 0.) ? 1 : 0;
         ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         fill_psd(ct.psd[h], L.psd);

@@ -58,6 +58,7 @@ struct ClassTable {
     int     dop_shared;            // Doppler moments ride on the polarimetric units (identical PSD)
     LutView lut[CPOL_MAX_CLASSES];
     LutView lut_dop[CPOL_MAX_CLASSES];
+    double  pol_x0[CPOL_MAX_CLASSES];         // D_0^nu of the polarimetric PSD
     double  dop_x0[CPOL_MAX_CLASSES];         // D_0^nu of the Doppler PSD as float32 (separate Doppler units)
     float   dop_geo_step[CPOL_MAX_CLASSES];
     float   pol_geo_step[CPOL_MAX_CLASSES];   // same for the polarimetric PSD   // 4 x diameter step when the Doppler PSD has nu = 1 on a uniform axis, else 0

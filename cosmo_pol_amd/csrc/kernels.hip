@@ -491,7 +491,7 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
 //   B'[d][j <  12] = sz[d][j] * D^mu                       (scattering_sz.py:95-103, PSD weight folded in)
 //   B'[d][12]      = rcs[d] * D^mu_d,  B'[d][13] = rcs[d] * v(D) * D^mu_d     (doppler_sz.py:192,218-220)
 // with rcs = 2 pi (sz0 - sz1 - sz2 + sz3) and v = alpha D^beta in float32 as in the reference.
-// xq[(q*4 + k)*4 + s] = D^nu in the same permuted order.
+// xq[(q*4 + k)*4 + s] = D^nu - D_0^nu in the same permuted order.
 // =============================================================================
 __global__ void k_build_image(const float *__restrict__ raw, const float *__restrict__ d_axis, float *__restrict__ img,
                               float *__restrict__ xq, long nslice, int ncol, double mu, double nu, int with_dop,
@@ -516,7 +516,9 @@ __global__ void k_build_image(const float *__restrict__ raw, const float *__rest
     }
     int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
     img[sl * 1024 * ncol + (((long)(q * 4 + k) * ncol + j) << 2) + s4] = val;
-    if (sl == 0 && j == 0) xq[((q * 4 + k) << 2) + s4] = (float)pow((double)D, nu);
+    // exponent argument relative to the first diameter: k_prep folds exp(-lambda D_0^nu) into the unit's
+    // coefficient in float64, so the float32 sums keep their leading terms however large lambda is
+    if (sl == 0 && j == 0) xq[((q * 4 + k) << 2) + s4] = (float)(pow((double)D, nu) - pow((double)d_axis[0], nu));
 }
 
 void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
@@ -671,8 +673,11 @@ __global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restr
             double l2 = l * 1.4426950408889634;            // exponent in base 2
             float hi = (float)l2;
             lam[(long)h * nu + u] = make_float2(hi, (float)(l2 - (double)hi));
-            coef[(long)h * nu + u] = n0 * (double)lv.dD * w;
-            if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = n0;
+            // the integration works with exp(-lambda (D^nu - D_0^nu)): the factor of the first diameter goes
+            // into the float64 coefficients
+            const double f0 = exp2(-l2 * ct.pol_x0[h]);
+            coef[(long)h * nu + u] = n0 * (double)lv.dD * w * f0;
+            if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = n0 * f0;
         }
         if (live) key[(long)h * nu + u] = k;
         // position of the unit inside its (bucket, shard) counter: one atomic per run of equal keys

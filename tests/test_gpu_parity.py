@@ -86,6 +86,33 @@ def test_observables_vs_oracle(scheme, n_gates, n_sub, att, dscheme):
     util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
 
 
+@pytest.mark.parametrize('scheme,dscheme', [(1, 0), (1, 2), (2, 2)])
+def test_observables_with_extreme_contents(scheme, dscheme):
+    """Mass and number densities scaled over 10 decades: the slope parameter of the size distributions then
+    runs from values for which N(D) is a float32 zero beyond the first few diameters to values for which it
+    never vanishes, all inside the same workgroup (the integration stops a wavefront at the last diameter any
+    of its units needs, and must give what the full 1024-term sum gives)."""
+    conf = O.make_config(microphysics={'scheme': scheme}, attenuation={'correction': 1}, doppler={'scheme': dscheme},
+                         radar={'radial_resolution': 500., 'frequency': 5.6})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(260, 9, scheme, seed=4242, res=500., zero_frac=0.1)
+    rng = np.random.default_rng(99)
+    for b in beams:
+        for k, v in b['values'].items():
+            if k.startswith('Q') and k.endswith('_v'):
+                v *= (10. ** rng.uniform(-8, 2, v.shape)).astype(np.float32)
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    luts = util.oracle_luts(scheme, 5.6)
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
+        if dscheme:
+            want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf)
+    check_obs(obs, want.values, 'extreme', res_km=0.5)
+    np.testing.assert_array_equal(mask, want.mask)
+    if dscheme:
+        util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+
+
 @pytest.mark.parametrize('ds', [1, 2, 3])
 def test_doppler_vs_golden(ds):
     """get_doppler_velocity (schemes 1, 2 and 3) against the reference's output."""
