@@ -488,8 +488,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
     launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
-                     (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p, (int *)ctx->b_rank.p,
-                     ctx->timing ? ctx->work_dev : nullptr);     // the ranks are spent: their buffer takes the row index
+                     (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p, ctx->timing ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
@@ -501,7 +500,6 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     op.row = CPOL_N_COL;
     Dop2In d2;
     memset(&d2, 0, sizeof(d2));
-    d2.rowidx = (const int *)ctx->b_rank.p;
     if (ctx->cfg.doppler_scheme == 2) {
         d2.vals = vals; d2.plane = plane; d2.elev = elev; d2.phi_sc = phi;
         d2.lam = (const float2 *)ctx->b_lam.p; d2.n0d = (const double *)ctx->b_n0d.p;

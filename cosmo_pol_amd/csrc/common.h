@@ -172,7 +172,7 @@ void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, int nb_r
                     const int *offs, const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
-                      int *rowidx, unsigned long long *work);
+                      unsigned long long *work);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
                           float2 *dop_out, long slot0);
@@ -197,7 +197,6 @@ struct Dop2In {                    // inputs of the Doppler scheme-2 reduction i
     const float2 *lam;
     const double *n0d;
     const float2 *dop_out;         // results of the separate Doppler units, indexed like their polarimetric twins
-    const int    *rowidx;          // row of psd_out holding a polarimetric slot's sums (written by k_integrate)
     int n_cls, ne_max, nt_max, shared;
     int slice_floats;              // floats per (e, t) node of that image
     int at0[2], at1[2];            // offsets of the two Doppler columns at d = 0 and d = 1023 inside a node

@@ -880,7 +880,7 @@ template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                  const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out,
-                 int *__restrict__ rowidx, unsigned long long *__restrict__ work)
+                 unsigned long long *__restrict__ work)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
@@ -922,8 +922,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 68) s_hist[tid] = 0;
     float2 lu = make_float2(0.f, 0.f);
-    int myslot = 0;
-    if (tid < cnt) { myslot = sorted[start + tid]; lu = lam[myslot]; }
+    if (tid < cnt) lu = lam[sorted[start + tid]];
     __syncthreads();
 
     // ---- order the chunk's units by where their N(D) becomes an exact float32 zero ----
@@ -956,7 +955,6 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     if (tid < cnt) {
         const int pos = s_hist[nqu] + myrank;
         s_perm[pos] = (unsigned char)tid;
-        rowidx[myslot] = start + pos;
     }
     __syncthreads();
 
@@ -968,11 +966,16 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         const int n4 = ((nq_chunk + 3) & ~3) * 4 * NC;
         constexpr int PER = SLICE_FLOATS / 4 / INTEG_THREADS;
         static_assert(SLICE_FLOATS % (4 * INTEG_THREADS) == 0, "slice must be a whole number of 16-byte rounds");
-        float4 v[PER];
-#pragma unroll
-        for (int i = 0; i < PER; i++) if (tid + i * INTEG_THREADS < n4) v[i] = src[tid + i * INTEG_THREADS];
-#pragma unroll
-        for (int i = 0; i < PER; i++) if (tid + i * INTEG_THREADS < n4) dst[tid + i * INTEG_THREADS] = v[i];
+        static_assert(PER % 2 == 0, "rounds are issued in pairs");
+        // whole rounds of one 16-byte word per thread (the last one may reach past n4, never past the slice),
+        // two loads in flight per thread
+        const int rounds = (n4 + INTEG_THREADS - 1) / INTEG_THREADS;
+        for (int i = 0; i < rounds; i += 2) {
+            const float4 a = src[tid + i * INTEG_THREADS];
+            const float4 b = src[tid + min(i + 1, PER - 1) * INTEG_THREADS];
+            dst[tid + i * INTEG_THREADS] = a;
+            if (i + 1 < rounds) dst[tid + (i + 1) * INTEG_THREADS] = b;
+        }
     }
     __syncthreads();
 
@@ -1109,13 +1112,11 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             for (int r = 0; r < 4; r++) {
                 int row = kq * 4 + r;
                 int u0 = g0 * 16 + row, u1 = u0 + 16;
-                // result rows of 16 floats (the spare columns hold zeros), stored in the chunk's cutoff order:
-                // a tile's 16 rows are then contiguous and leave as whole cache lines (rows placed by slot
-                // would be scattered partial-line writes, each costing a fill and a write-back); rowidx
-                // tells the readers where a slot's row went
+                // result rows of 16 floats (the spare columns hold zeros): one aligned 64-byte write per unit,
+                // wherever the cutoff order scattered the pass's units over the slots
                 constexpr int ROW = CPOL_N_COL;
-                if (u0 < cnt) psd_out[(long)(start + u0) * ROW + j] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)(start + u1) * ROW + j] = (float)db[r];
+                if (u0 < cnt) psd_out[(long)sorted[start + s_perm[u0]] * ROW + j] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)sorted[start + s_perm[u1]] * ROW + j] = (float)db[r];
             }
         }
     }
@@ -1126,16 +1127,16 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
-                      int *rowidx, unsigned long long *work)
+                      unsigned long long *work)
 {
     if (max_chunks <= 0) return;
     max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
     if (ct.ncol == 12)
         hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, lam, psd_out, rowidx, work);
+                           chunk_bucket, sorted, lam, psd_out, work);
     else
         hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, lam, psd_out, rowidx, work);
+                           chunk_bucket, sorted, lam, psd_out, work);
 }
 
 // =============================================================================
@@ -1327,8 +1328,7 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
         any = true;
         double s12, s13;
         if (d2.shared) {
-            const long row = d2.rowidx[pslot];
-            s12 = (double)psd_out[row * CPOL_N_COL + 12]; s13 = (double)psd_out[row * CPOL_N_COL + 13];
+            s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13];
         }
         else { const float2 t = d2.dop_out[pslot]; s12 = (double)t.x; s13 = (double)t.y; }
         if (d2.shared) {
@@ -1381,7 +1381,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const int *__restrict__ ke
             long slot = (long)h * nu + u;
             if (key[slot] < 0) continue;
             double c = coef[slot];
-            const float4 *p = (const float4 *)(psd_out + (long)d2.rowidx[slot] * op.row);
+            const float4 *p = (const float4 *)(psd_out + slot * op.row);
             float4 v0 = p[0], v1 = p[1], v2 = p[2];
             const float vv[CPOL_N_SZ] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
 #pragma unroll
