@@ -251,6 +251,8 @@ def main():
             'stage_ms_per_step': {k: v / args.steps for k, v in tim['ms'].items()},
             'valid_units_per_step': tim['valid_units'] / args.steps,
             'doppler_units_per_step': tim['doppler_units'] / args.steps,
+            'doppler_evaluated_fraction': (tim['doppler_unit_diameters'] / (1024. * tim['doppler_units'])
+                                           if tim['doppler_units'] else None),
             'finite_zh_fraction': finite, 'finite_rvel_fraction': finite_rvel,
             'cpu_baseline': cpu,
         }

@@ -81,7 +81,7 @@ def load():
     lib.cpol_synchronize.argtypes = [vp]
     lib.cpol_timing_enable.argtypes = [vp, C.c_int]
     lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
-    lib.cpol_timing_work.argtypes = [vp, c_double_p]
+    lib.cpol_timing_work.argtypes = [vp, c_double_p, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
@@ -174,10 +174,11 @@ class Context(object):
         nl = (C.c_long * len(self.STAGES))()
         vu, du = C.c_double(), C.c_double()
         self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu), C.byref(du)), 'cpol_timing_read')
-        wk = C.c_double()
-        self._check(self.lib.cpol_timing_work(self.h, C.byref(wk)), 'cpol_timing_work')
+        wk, wd = C.c_double(), C.c_double()
+        self._check(self.lib.cpol_timing_work(self.h, C.byref(wk), C.byref(wd)), 'cpol_timing_work')
         return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
-                'valid_units': vu.value, 'doppler_units': du.value, 'evaluated_unit_diameters': wk.value}
+                'valid_units': vu.value, 'doppler_units': du.value, 'evaluated_unit_diameters': wk.value,
+                'doppler_unit_diameters': wd.value}
 
     def set_batch_units(self, n):
         self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')

@@ -73,8 +73,8 @@ extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     timing_collect(ctx);
-    if (on && !ctx->work_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->work_dev, 64 * sizeof(unsigned long long)));
-    if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, 64 * sizeof(unsigned long long)));
+    if (on && !ctx->work_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->work_dev, 128 * sizeof(unsigned long long)));
+    if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, 128 * sizeof(unsigned long long)));
     ctx->timing = on != 0;
     for (int i = 0; i < CPOL_N_STAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_launches[i] = 0; }
     ctx->valid_units = 0; ctx->dop_units = 0;
@@ -97,18 +97,20 @@ extern "C" int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], l
     return CPOL_OK;
 }
 
-extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters)
+extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters)
 {
     if (!ctx || !evaluated_unit_diameters) return CPOL_ERR_ARG;
     *evaluated_unit_diameters = 0.;
+    if (doppler_unit_diameters) *doppler_unit_diameters = 0.;
     if (!ctx->work_dev) return CPOL_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long w[64];
+    unsigned long long w[128];
     HIPCHK(ctx, hipMemcpy(w, ctx->work_dev, sizeof(w), hipMemcpyDeviceToHost));
-    double tot = 0.;
-    for (int i = 0; i < 64; i++) tot += (double)w[i];
+    double tot = 0., totd = 0.;
+    for (int i = 0; i < 64; i++) { tot += (double)w[i]; totd += (double)w[64 + i]; }
     *evaluated_unit_diameters = 16. * tot;
+    if (doppler_unit_diameters) *doppler_unit_diameters = 16. * totd;
     return CPOL_OK;
 }
 
@@ -395,6 +397,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
         for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
         ct.cut_ok[h] = (asc && L.psd.nu > 0.) ? 1 : 0;
+        ct.dop_cut_ok[h] = (asc && L.psd_dop.nu > 0.) ? 1 : 0;
         ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         fill_psd(ct.psd[h], L.psd);
@@ -493,7 +496,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
         launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
-                             (const float2 *)ctx->b_lam.p, (float2 *)ctx->b_dop.p, (long)ct.n_cls * nu);
+                             (const float2 *)ctx->b_lam.p, (const double *)ctx->b_n0d.p, (float2 *)ctx->b_dop.p, (long)ct.n_cls * nu,
+                             ctx->timing ? ctx->work_dev : nullptr);
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);

@@ -65,6 +65,7 @@ struct ClassTable {
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
     int     cut_ok[CPOL_MAX_CLASSES];          // D^nu ascending along the diameter axis
+    int     dop_cut_ok[CPOL_MAX_CLASSES];      // same for the Doppler PSD's nu
 };
 
 struct ModelView {
@@ -129,7 +130,7 @@ struct cpol_ctx {
         o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     size_t max_batch_units = (size_t)16 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
-    unsigned long long *work_dev = nullptr;       // 64 partial counts of unit x 16-diameter steps k_integrate evaluated (timing only)
+    unsigned long long *work_dev = nullptr;       // 2 x 64 partial counts of unit x 16-diameter steps evaluated by k_integrate / k_integrate_dop (timing only)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -175,7 +176,7 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
                       unsigned long long *work);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
-                          float2 *dop_out, long slot0);
+                          const double *n0d, float2 *dop_out, long slot0, unsigned long long *work);
 void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                             double mu_d, double nu_d, double alpha_d, double beta_d);
 struct SpecParams {

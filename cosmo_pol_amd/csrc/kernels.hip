@@ -1149,13 +1149,13 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
 // =============================================================================
 #define DOP_THREADS (CPOL_CHUNK_UNITS / 2)      // two units per lane: every LDS word read serves both
 
-// plain path of one unit: one exponential per diameter
-__device__ inline void dop_unit_plain(const float *lds, float2 l, double *o12, double *o13)
+// plain path of one unit: one exponential per diameter, over the first nq8 quads (a multiple of 8)
+__device__ inline void dop_unit_plain(const float *lds, float2 l, int nq8, double *o12, double *o13)
 {
     const float4 *I4 = (const float4 *)lds;
     const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
     double s12 = 0., s13 = 0.;
-    for (int wo = 0; wo < 256; wo += 32) {
+    for (int wo = 0; wo < 4 * nq8; wo += 32) {
         f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
 #pragma unroll 4
         for (int w = wo; w < wo + 32; w++) {
@@ -1179,16 +1179,20 @@ __device__ inline void dop_unit_plain(const float *lds, float2 l, double *o12, d
 
 __global__ __launch_bounds__(DOP_THREADS)
 void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                     const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float2 *__restrict__ dop_out,
-                     long slot0)
+                     const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam,
+                     const double *__restrict__ n0d, float2 *__restrict__ dop_out, long slot0,
+                     unsigned long long *__restrict__ work)
 {
     __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
+    __shared__ int s_hist[68];
+    __shared__ unsigned char s_perm[CPOL_CHUNK_UNITS], s_nq[CPOL_CHUNK_UNITS];
     const int c_lo = chunk_off[b_lo];
     const unsigned total = (unsigned)(chunk_off[b_hi] - c_lo);
-    const unsigned orig = blockIdx.x;
-    if (orig >= total) return;
-    const unsigned q8 = total / 8, r8 = total % 8, xcd = orig % 8;
-    const int cid = c_lo + (int)((xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8);
+    // runs of INTEG_XCD_RUN consecutive chunks go round the XCDs, as in k_integrate
+    const unsigned xcd = blockIdx.x % 8, kx = blockIdx.x / 8;
+    const unsigned rel = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
+    if (rel >= total) return;
+    const int cid = c_lo + (int)rel;
     const int lo = chunk_bucket[cid];               // bucket of this chunk (k_fill_chunks)
     const int bkt = lo;
     const int start = offs[bkt] + (cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
@@ -1205,16 +1209,69 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 #pragma unroll
         for (int i = 0; i < CPOL_DOP_SLICE / 4 / DOP_THREADS; i++) dst[tid + i * DOP_THREADS] = src[tid + i * DOP_THREADS];
     }
+    if (tid < 68) s_hist[tid] = 0;
     __syncthreads();
-    // units tid and tid + DOP_THREADS of the chunk
-    const bool have[2] = {tid < cnt, tid + DOP_THREADS < cnt};
-    if (!have[0]) return;
+    // ---- order the chunk's units by how many quads of 16 diameters they need (as k_integrate does): none for
+    // a unit whose N0 is an exact zero (its moments are multiplied by it: the 1-moment snow intercept fed
+    // with a number concentration for a temperature, doppler_sz.py:57, underflows for most gates), else up to
+    // where its N(D) becomes an exact float32 zero.  A wavefront stops at the last quad any of its 128 units
+    // needs. ----
+    const bool cut_ok = ct.dop_cut_ok[h];
+    int nqu[2], myrank[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = tid + t * DOP_THREADS;
+        nqu[t] = 64; myrank[t] = 0;
+        if (i < cnt) {
+            const int sl = sorted[start + i];
+            if (n0d[sl] == 0.) nqu[t] = 0;
+            else if (cut_ok) {
+                const float2 lt = lam[sl];
+                const float xc = psd_cutoff_x(lt.x + lt.y);
+                int c = 0;
+#pragma unroll
+                for (int step = 64; step >= 1; step >>= 1)
+                    if (c + step <= 64 && lds[12 * 4 * (c + step - 1)] <= xc) c += step;     // first D^nu - D_0^nu of a quad
+                nqu[t] = c;
+            }
+            myrank[t] = atomicAdd(&s_hist[nqu[t]], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int hh = s_hist[tid];
+        int incl = hh;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { int o = __shfl_up(incl, m); if (tid >= m) incl += o; }
+        s_hist[tid] = incl - hh;
+        if (tid == 63) s_hist[64] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = tid + t * DOP_THREADS;
+        if (i < cnt) { const int pos = s_hist[nqu[t]] + myrank[t]; s_perm[pos] = (unsigned char)i; s_nq[pos] = (unsigned char)nqu[t]; }
+    }
+    __syncthreads();
+    // a wavefront takes 128 consecutive positions of that order, a lane positions p and p + 64 of them
+    const int wbase = (tid >> 6) * 128, lane = tid & 63;
+    const int pos[2] = {wbase + lane, wbase + 64 + lane};
+    const bool have[2] = {pos[0] < cnt, pos[1] < cnt};
+    if (wbase >= cnt) return;
+    const int nq8 = (s_nq[min(wbase + 127, cnt - 1)] + 7) & ~7;
+    if (work && lane == 0) atomicAdd(&work[64 + (blockIdx.x & 63)], (unsigned long long)nq8 * (unsigned)min(cnt - wbase, 128));
     int slot[2];
     float2 l[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        slot[t] = have[t] ? sorted[start + tid + t * DOP_THREADS] : 0;
+        slot[t] = have[t] ? sorted[start + s_perm[pos[t]]] : 0;
         l[t] = have[t] ? lam[slot[t]] : make_float2(0.f, 0.f);
+    }
+    if (nq8 == 0) {          // nothing to integrate for any unit of the wavefront
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+            if (have[t]) dop_out[(long)slot[t] - slot0] = make_float2(0.f, 0.f);
+        return;
     }
     const float4 *I4 = (const float4 *)lds;
     double s12[2] = {0., 0.}, s13[2] = {0., 0.};
@@ -1232,7 +1289,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
             R2[t] = (f32x2){rs, rs};
             R4[t] = R2[t] * R2[t];
         }
-        for (int qo = 0; qo < 64; qo += 8) {
+        for (int qo = 0; qo < nq8; qo += 8) {
             f32x2 a12[2] = {{0.f, 0.f}, {0.f, 0.f}}, a13[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1271,7 +1328,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         }
     } else {
         for (int t = 0; t < 2; t++)
-            if (have[t]) dop_unit_plain(lds, l[t], &s12[t], &s13[t]);
+            if (have[t]) dop_unit_plain(lds, l[t], nq8, &s12[t], &s13[t]);
     }
     // unit-spacing trapezoid rule (doppler_sz.py:219-220): the sum minus half of the two end terms
     const int wl = 12 * 255 + 3;                 // d = 1023 is the last element of the last word
@@ -1288,11 +1345,13 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 }
 
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
-                          const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float2 *dop_out, long slot0)
+                          const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
+                          const double *n0d, float2 *dop_out, long slot0, unsigned long long *work)
 {
     if (max_chunks <= 0) return;
+    max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
     hipLaunchKernelGGL(k_integrate_dop, dim3((unsigned)max_chunks), dim3(DOP_THREADS), 0, s, ct, b_lo, b_hi, offs,
-                       chunk_off, chunk_bucket, sorted, lam, dop_out, slot0);
+                       chunk_off, chunk_bucket, sorted, lam, n0d, dop_out, slot0, work);
 }
 
 // =============================================================================

@@ -115,8 +115,9 @@ int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_l
  * N(D) = exp(-lambda D^nu) underflows to an exact float32 zero beyond some diameter; units are ordered by
  * that diameter inside their bucket and a wavefront stops at the last 16-diameter step any of its units
  * still needs, so this is less than 1024 x valid_units (no counterpart in the reference, which evaluates
- * all 1024 terms in float64, scattering_sz.py:95-103). */
-int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters);
+ * all 1024 terms in float64, scattering_sz.py:95-103).  doppler_unit_diameters (may be NULL): the same for
+ * stage INTEGRATE_DOP, where a unit whose N0 is an exact zero needs no term at all. */
+int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters);
 /* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
  * workspace the library allocates (default 16 Mi positions, about 13 GB with 2-moment input and Doppler scheme 2). */
 int cpol_set_batch_units(cpol_ctx *ctx, long max_units);
