@@ -581,7 +581,7 @@ static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)
     TRY(ensure(ctx, ctx->b_lat, nu * sizeof(double)));
     TRY(ensure(ctx, ctx->b_lon, nu * sizeof(double)));
     TRY(ensure(ctx, ctx->b_coords, nu * 2 * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_line, (size_t)nrb * 28 * sizeof(double)));
+    TRY(ensure(ctx, ctx->b_line, (size_t)nrb * CPOL_LINE_N * sizeof(double)));
     TRY(ensure(ctx, ctx->b_phi, (size_t)nrb * 2 * sizeof(double)));
     return CPOL_OK;
 }

@@ -42,7 +42,7 @@ void launch_transpose_levels(hipStream_t s, const float *src, float *dst, int nz
 // pyproj Geod.fwd does at interpolation.py:322-325; Karney 2013 series, order 6),
 // rotated-pole transform (interpolation.py:355).
 // =============================================================================
-#define LINE_N 28
+#define LINE_N CPOL_LINE_N
 
 __device__ inline double polyv(int n, const double *p, double x)
 {
@@ -204,6 +204,12 @@ __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict_
     for (int l = 1; l <= 6; ++l) L[12 + l] = C1pa[l];
     for (int l = 1; l <= 5; ++l) L[18 + l] = C3a[l];
     L[24] = el_b;
+    {   // per-line trigonometry of k_geom_pts: elevation of the 4/3 model, rotated-pole latitude
+        const double ela = el_b * M_PI / 180.;
+        L[26] = sin(ela); L[27] = cos(ela);
+        const double pollat = -gp.pole_lat_s;
+        L[28] = sin(pollat * DEG); L[29] = cos(pollat * DEG);
+    }
     if (gp.n_refr > 0) {
         // profile of this total elevation in the refraction table (exact key)
         int lo = 0, hi = gp.n_refr - 1;
@@ -238,7 +244,7 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
         // ---- refraction, 4/3 earth model (atm_refraction.py:110-123) ----
         double rr = gp.res / 2 + g * gp.res;                 // np.arange(res/2, range, res)
         double ela = L[24] * M_PI / 180.;
-        double sel = sin(ela), cel = cos(ela);
+        double sel = L[26], cel = L[27];
         const double ke = 4. / 3.;
         double keR = ke * gp.earth_radius;
         double Hd = sqrt(rr * rr + keR * keR + 2 * rr * ke * gp.earth_radius * sel) - keR + gp.alt;
@@ -277,9 +283,9 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     lat_out[u] = lat; lon_out[u] = lon;
 
     // ---- rotated pole (north pole from the southern-pole metadata) ----
-    double pollat = -gp.pole_lat_s, pollon = gp.pole_lon_s - 180.0;
+    double pollon = gp.pole_lon_s - 180.0;
     if (pollon < -180.0) pollon += 360.0;
-    double sp = sin(pollat * DEG), cp = cos(pollat * DEG);
+    double sp = L[28], cp = L[29];
     double ph = lat * DEG, dl = (lon - pollon) * DEG;
     double sphi = sin(ph), cphi = cos(ph), sdl = sin(dl), cdl = cos(dl);
     double a0 = cp * cphi * cdl + sp * sphi;
