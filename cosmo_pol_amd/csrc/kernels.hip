@@ -268,7 +268,12 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     double s = sin(tau12), c = cos(tau12);
     double B12 = -sin_cos_series(stau1 * c + ctau1 * s, ctau1 * c - stau1 * s, C1pa, 6);
     double sig12 = tau12 - (B12 - B11);
-    double ssig12 = sin(sig12), csig12 = cos(sig12);
+    // sin / cos of sig12 = tau12 + dlt from those of tau12: |dlt| < 3e-3 (series terms of order f), so five
+    // Taylor terms are exact to 1e-19
+    const double dlt = -(B12 - B11), dl2 = dlt * dlt;
+    const double sdlt = dlt * (1. + dl2 * (-1. / 6. + dl2 * (1. / 120.)));
+    const double cdlt = 1. + dl2 * (-0.5 + dl2 * (1. / 24. - dl2 * (1. / 720.)));
+    double ssig12 = s * cdlt + c * sdlt, csig12 = c * cdlt - s * sdlt;
     double ssig2 = ssig1 * csig12 + csig1 * ssig12;
     double csig2 = csig1 * csig12 - ssig1 * ssig12;
     double sbet2 = calp0 * ssig2;
@@ -286,8 +291,10 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     double pollon = gp.pole_lon_s - 180.0;
     if (pollon < -180.0) pollon += 360.0;
     double sp = L[28], cp = L[29];
-    double ph = lat * DEG, dl = (lon - pollon) * DEG;
-    double sphi = sin(ph), cphi = cos(ph), sdl = sin(dl), cdl = cos(dl);
+    double dl = (lon - pollon) * DEG;
+    // lat = atan2(sbet2, f1 cbet2): its sine and cosine are that pair normalised
+    const double hphi = hypot(sbet2, f1 * cbet2);
+    double sphi = sbet2 / hphi, cphi = f1 * cbet2 / hphi, sdl = sin(dl), cdl = cos(dl);
     double a0 = cp * cphi * cdl + sp * sphi;
     double a1 = -sdl * cphi;
     double a2 = -sp * cphi * cdl + cp * sphi;
