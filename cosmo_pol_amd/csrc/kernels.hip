@@ -398,17 +398,51 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             if (above) code = -1;
             else {
                 int cnt[4] = {0, 0, 0, 0};
+                // column 0 by bisection; the levels of the three neighbours lie close to it (terrain-following
+                // coordinates), so their counts are read off a window of four heights around column 0's
+                // count, and only a column whose window does not bracket H is bisected as well
                 for (int step = 1 << (31 - __clz(nz)); step > 0; step >>= 1) {
-                    float v[4];
-                    bool in[4];
+                    const bool in = cnt[0] + step <= nz;
+                    const float v = col[0][in ? cnt[0] + step - 1 : 0];
+                    if (in && v >= H) cnt[0] += step;
+                }
+                bool redo[4] = {false, false, false, false};
+                {
+                    const int lo = cnt[0] - 2;
+                    float w[3][4];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        in[j] = cnt[j] + step <= nz;
-                        v[j] = col[j][in[j] ? cnt[j] + step - 1 : 0];
+                    for (int j = 1; j < 4; j++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int idx = min(max(lo + k, 0), nz - 1);
+                            w[j - 1][k] = col[j][idx];
+                        }
+#pragma unroll
+                    for (int j = 1; j < 4; j++) {
+                        const bool lower_ok = lo <= 0 || w[j - 1][0] >= H;         // every level above the window is >= H
+                        const bool upper_ok = lo + 3 >= nz - 1 || w[j - 1][3] < H; // every level below it is < H
+                        int c = max(lo, 0);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int idx = lo + k;
+                            if (idx >= 0 && idx <= nz - 1 && w[j - 1][k] >= H) c++;
+                        }
+                        cnt[j] = c;
+                        redo[j] = !(lower_ok && upper_ok);
+                    }
+                }
+                if (redo[1] || redo[2] || redo[3]) {
+                    int c2[4] = {0, 0, 0, 0};
+                    for (int step = 1 << (31 - __clz(nz)); step > 0; step >>= 1) {
+#pragma unroll
+                        for (int j = 1; j < 4; j++) {
+                            const bool in = c2[j] + step <= nz;
+                            const float v = col[j][in ? c2[j] + step - 1 : 0];
+                            if (in && v >= H) c2[j] += step;
+                        }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (in[j] && v[j] >= H) cnt[j] += step;
+                    for (int j = 1; j < 4; j++) if (redo[j]) cnt[j] = c2[j];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
