@@ -139,3 +139,8 @@ def test_bench_line_contract(capsys, monkeypatch):
     assert set(('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')) <= set(d['roofline'])
     assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-12
     assert d['value'] > 0 and d['steps'] == 1 and d['warmup'] == 1
+    # the roofline prices the terms the integration evaluated; the skipped ones are exact float32 zeros
+    ev = d['roofline']['evaluated_fraction']
+    assert 0. < ev <= 1.
+    assert abs(d['roofline']['algorithmic_tflops'] * ev - d['roofline']['achieved']) < 1e-9 * d['roofline']['achieved']
+    assert d['doppler_evaluated_fraction'] is None or 0. < d['doppler_evaluated_fraction'] <= 1.
