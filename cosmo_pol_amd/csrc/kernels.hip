@@ -499,6 +499,9 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int pos = 2 * (p8 + i) + (lane >> 5);
+                // nothing to do for a pair of points that both lie outside the model (the tail of a ray above
+                // the model top, the gates below the terrain): their outputs are sentinels
+                if (!__any(s_code[wv][pos] == 0)) continue;
                 // vertical interpolation of the lane's two columns (interpolation_c.c:151)
                 const float w0 = vb[i][0] - (vb[i][0] - va[i][0]) / s_fz[wv][c0][pos] * s_hz[wv][c0][pos];
                 const float w1 = vb[i][1] - (vb[i][1] - va[i][1]) / s_fz[wv][c1_][pos] * s_hz[wv][c1_][pos];
