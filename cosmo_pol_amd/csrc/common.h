@@ -8,7 +8,7 @@
 
 #define CPOL_WAVE 64
 #define CPOL_CHUNK_UNITS 256      // units (gate x sub-beam x class) per integrate workgroup
-#define CPOL_SORT_SHARDS 16         // counters per bucket: spreads same-address atomics of big buckets
+#define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_LINE_N 32            // doubles per (ray, sub-beam) record of the geodesic line constants
 #define CPOL_N_COL 16             // MFMA N dimension: 12 scattering components + 4 spare columns
