@@ -469,7 +469,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
                 (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
                 (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->b_cbkt.p);
-    launch_scatter(ctx->stream, nu, n_planes, ct.n_cls, nb_pol, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
+    launch_scatter(ctx->stream, nu, ct.n_cls, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
                    (int *)ctx->b_sorted.p);
     }
     if (ctx->timing) {

@@ -170,8 +170,8 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
                  int *chunk_bucket);
-void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, int nb_ranked, const int *key, const int *rank,
-                    const int *offs, const int *cursor, int *sorted);
+void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *offs,
+                    const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
                       unsigned long long *work);

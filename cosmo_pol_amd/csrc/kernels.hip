@@ -883,29 +883,25 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
     hipLaunchKernelGGL(k_fill_chunks, dim3(nb), dim3(64), 0, s, chunk_off, chunk_bucket);
 }
 
-// Final position of every valid unit = bucket start + start of its shard inside the bucket + the rank
-// k_prep drew.
-__global__ void k_scatter(long nu, int n_ranked, int nb_ranked, const int *__restrict__ key, const int *__restrict__ rank,
+// Final position of every valid polarimetric unit = bucket start + start of its shard inside the bucket + the
+// rank k_prep drew.
+__global__ void k_scatter(long nu, const int *__restrict__ key, const int *__restrict__ rank,
                           const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
-    const int pl = blockIdx.y;
-    // planes beyond n_ranked (separate Doppler units) have the key of their polarimetric twin moved up by the
-    // number of polarimetric buckets, and the twin's rank
-    const long twin = (long)(pl < n_ranked ? pl : pl - n_ranked) * nu + u;
-    int k = key[twin];
+    const int pl = blockIdx.y;                 // polarimetric planes only: the separate Doppler units follow their twins
+    const long slot = (long)pl * nu + u;
+    const int k = key[slot];
     if (k < 0) return;
-    if (pl >= n_ranked) k += nb_ranked;
-    sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[twin]] =
-        (int)((long)pl * nu + u);
+    sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
 }
 
-void launch_scatter(hipStream_t s, long nu, int n_planes, int n_ranked, int nb_ranked, const int *key, const int *rank,
-                    const int *offs, const int *cursor, int *sorted)
+void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *offs,
+                    const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_planes), dim3(256), 0, s, nu, n_ranked, nb_ranked,
-                       key, rank, offs, cursor, sorted);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_cls), dim3(256), 0, s, nu, key, rank, offs, cursor,
+                       sorted);
 }
 
 // =============================================================================
@@ -1245,9 +1241,12 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     const int cid = c_lo + (int)rel;
     const int lo = chunk_bucket[cid];               // bucket of this chunk (k_fill_chunks)
     const int bkt = lo;
-    const int start = offs[bkt] + (cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
-    int cnt = offs[bkt + 1] - start;
+    const int rel0 = (cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
+    int cnt = offs[bkt + 1] - offs[bkt] - rel0;
     if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
+    // a Doppler bucket holds the twins of the polarimetric bucket b_lo below it, in the same order: its units
+    // are that bucket's entries of the sorted list moved up by slot0 (k_scatter writes no list of their own)
+    const int start = offs[bkt - b_lo] + rel0;
     const int it = bkt % ct.nt_max;
     const int ie = (bkt / ct.nt_max) % ct.ne_max;
     const int h = bkt / (ct.nt_max * ct.ne_max) - ct.n_cls;
@@ -1273,7 +1272,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         const int i = tid + t * DOP_THREADS;
         nqu[t] = 64; myrank[t] = 0;
         if (i < cnt) {
-            const int sl = sorted[start + i];
+            const int sl = sorted[start + i] + (int)slot0;
             if (n0d[sl] == 0.) nqu[t] = 0;
             else if (cut_ok) {
                 const float2 lt = lam[sl];
@@ -1314,7 +1313,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     float2 l[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        slot[t] = have[t] ? sorted[start + s_perm[pos[t]]] : 0;
+        slot[t] = have[t] ? sorted[start + s_perm[pos[t]]] + (int)slot0 : 0;
         l[t] = have[t] ? lam[slot[t]] : make_float2(0.f, 0.f);
     }
     if (nq8 == 0) {          // nothing to integrate for any unit of the wavefront
