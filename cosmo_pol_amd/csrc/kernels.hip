@@ -910,6 +910,11 @@ void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int
 // as an [units x 1024] . [1024 x 16] contraction on the f32 matrix cores
 // (v_mfma_f32_16x16x4_f32).  The bucket's table slice lives in LDS; every lane
 // generates one N(D) value per MFMA (A operand), so nothing is computed twice.
+// exp(-lambda (D^nu - D_0^nu)) is an exact float32 zero beyond a unit's cutoff diameter
+// (psd_cutoff_x): the workgroup orders its units by that cutoff, stages only the part of
+// the slice its largest cutoff needs and runs passes of 32 units, each up to the cutoff of
+// its last unit.  The skipped terms are exact zeros, so a unit's sums do not depend on
+// which units share its pass.
 // =============================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -948,8 +953,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const unsigned cid = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
     if (cid >= total) return;
 
-    const int lo = chunk_bucket[cid];               // bucket of this chunk (k_fill_chunks)
-    const int bkt = lo;
+    const int bkt = chunk_bucket[cid];              // bucket of this chunk (k_fill_chunks)
     const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
     int cnt = offs[bkt + 1] - start;
     if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
