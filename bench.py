@@ -38,7 +38,7 @@ FLOP_PER_UNIT = 27 * N_D          # 12 components x (mul + add) + 3 for N(D), pe
 FLOP_PER_UNIT_DOP2 = 6 * N_D      # Doppler scheme 2: two more columns (N rcs, N v rcs), mul + add + weight each
 
 
-def workload_config(small=False, doppler=2, microphysics=2):
+def workload_config(small=False, doppler=2, microphysics=2, n_gh=3):
     from cosmo_pol_amd import cfg
     # Monte Lema's position; the altitude is 80 m above the synthetic terrain at that grid cell (a radar below
     # the terrain would see NaN air density at its first gate, which the reference turns into NaN RVEL for
@@ -46,7 +46,7 @@ def workload_config(small=False, doppler=2, microphysics=2):
     conf = {'radar': {'coords': [46.04079, 8.83321, 2050], 'type': 'ground', 'frequency': 5.6,
                       'range': 250000, 'radial_resolution': 500, 'PRI': 700, 'FFT_length': 128,
                       'sensitivity': [-15, 10000], '3dB_beamwidth': 1.},
-            'integration': {'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.},
+            'integration': {'scheme': 1, 'nh_GH': n_gh, 'nv_GH': n_gh, 'weight_threshold': 1.},
             'refraction': {'scheme': 1}, 'attenuation': {'correction': 1}, 'doppler': {'scheme': doppler},
             'microphysics': {'scheme': microphysics}}
     if small:
@@ -116,6 +116,8 @@ def main():
     ap.add_argument('--doppler', type=int, choices=[0, 1, 2], default=2, help='doppler.scheme of the workload')
     ap.add_argument('--microphysics', type=int, choices=[1, 2], default=2,
                     help='2 = the headline 2-moment workload; 1 = the same volume with 1-moment input (3 classes)')
+    ap.add_argument('--gh', type=int, default=3, help='Gauss-Hermite nodes per direction: 3 = the 9 sub-beams of the headline '
+                    'workload, 9 = the 81 sub-beams of the literal CH_PPI_lema.yml (secondary run)')
     ap.add_argument('--batch-units', type=int, default=0, help='positions per internal batch (0 = library default)')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
     args = ap.parse_args()
@@ -125,7 +127,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
     from cosmo_pol_amd import synthetic as syn
-    conf = workload_config(args.small, args.doppler, args.microphysics)
+    conf = workload_config(args.small, args.doppler, args.microphysics, args.gh)
     azs, elv = volume_rays(args.small)
     shape = (80, 774, 1158) if not args.small else (24, 200, 240)
     model = syn.synthetic_model(*shape, scheme=args.microphysics, seed=20161111 + (rank if args.scaling == 'weak' else 0),
@@ -237,9 +239,10 @@ def main():
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
             'config': {'workload': 'CH_PPI_lema volume: 20 elevations x 360 azimuths x %d gates, COSMO-1 grid '
-                                   '%dx%dx%d, %d-moment (%d classes), 3x3 Gauss-Hermite (9 sub-beams), attenuation on, '
+                                   '%dx%dx%d, %d-moment (%d classes), %dx%d Gauss-Hermite (%d sub-beams), attenuation on, '
                                    'Doppler scheme %d%s' % (G, shape[2], shape[1], shape[0], args.microphysics,
-                                                            args.microphysics + 2, args.doppler,
+                                                            args.microphysics + 2, args.gh, args.gh, eng.ctx.n_sub,
+                                                            args.doppler,
                                                             ' [SMALL DEBUG RUN - INVALID]' if args.small else ''),
                        'rays_per_rank': R, 'gates': G, 'sub_beams': eng.ctx.n_sub, 'classes': args.microphysics + 2,
                        'parallelism': 'rays sharded, %d rank(s)' % world},
