@@ -452,7 +452,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->b_key, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_sorted, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
     TRY(ensure(ctx, ctx->b_rank, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));

@@ -29,7 +29,6 @@ struct LutDev {
     float  d0 = 0;                 // first diameter
     std::vector<float> d_host;     // the diameter axis as uploaded
     int    image_ncol = 0;         // what `table` was last built for
-    bool   image_dop = false;
     cpol_psd psd, psd_dop;
 };
 
