@@ -347,6 +347,15 @@ static bool same_psd(const cpol_psd &a, const cpol_psd &b)
            (a.psd_kind != 1 || a.t_var == b.t_var || (a.t_var < 0 && b.t_var < 0));
 }
 
+// Reference point of the exponent argument: the smallest D^nu of the diameter axis (D_0^nu for the reference's
+// ascending axes), so that exp(-lambda (D^nu - x_ref)) never exceeds 1.
+static double xref_of(const LutDev &L, double nu)
+{
+    double m = pow((double)L.d0, nu);
+    for (float d : L.d_host) { double x = pow((double)d, nu); if (x < m) m = x; }
+    return m;
+}
+
 // Class table of the configured schemes; (re)builds the lookup-table images when the column
 // layout they were built for differs from what the configuration needs.
 static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
@@ -375,11 +384,11 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
             if (!L.xq_dop) HIPCHK(ctx, hipMalloc((void **)&L.xq_dop, 1024 * sizeof(float)));
             HIPCHK(ctx, hipMalloc((void **)&L.table, img_bytes));
             launch_build_image(ctx->stream, L.raw, L.d_axis, L.table, L.xq, nslice, ct.ncol, L.psd.mu, L.psd.nu,
-                               shared ? 1 : 0, 0, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta);
+                               shared ? 1 : 0, 0, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta, xref_of(L, L.psd.nu));
             if (want_dop_img) {
                 HIPCHK(ctx, hipMalloc((void **)&L.table_dop, (size_t)nslice * CPOL_DOP_SLICE * sizeof(float)));
                 launch_build_dop_image(ctx->stream, L.raw, L.d_axis, L.table_dop, L.xq_dop, nslice, L.psd_dop.mu,
-                                       L.psd_dop.nu, L.psd_dop.alpha, L.psd_dop.beta);
+                                       L.psd_dop.nu, L.psd_dop.alpha, L.psd_dop.beta, (double)(float)xref_of(L, L.psd_dop.nu));
             }
             HIPCHK(ctx, hipGetLastError());
             L.image_ncol = tag;
@@ -391,8 +400,8 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
         // exponential per four diameters
-        ct.pol_x0[h] = pow((double)L.d0, L.psd.nu);
-        ct.dop_x0[h] = (double)(float)pow((double)L.d0, L.psd_dop.nu);
+        ct.pol_x0[h] = xref_of(L, L.psd.nu);
+        ct.dop_x0[h] = (double)(float)xref_of(L, L.psd_dop.nu);
         // N(D) = 0 in float32 beyond a unit's cutoff needs D^nu ascending along the axis
         bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
         for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];

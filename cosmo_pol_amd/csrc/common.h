@@ -165,7 +165,7 @@ void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, cons
                  int *hist, double *vr);
 void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                         int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
-                        double beta_d);
+                        double beta_d, double x_ref);
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
                  int *chunk_bucket);
@@ -178,7 +178,7 @@ void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, 
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
                           const double *n0d, float2 *dop_out, long slot0, unsigned long long *work);
 void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
-                            double mu_d, double nu_d, double alpha_d, double beta_d);
+                            double mu_d, double nu_d, double alpha_d, double beta_d, double x_ref);
 struct SpecParams {
     int    n_gates, n_sub, n_vel;
     float  zfac;                   // wavelength^4 / (pi^5 KW^2) as float32

@@ -545,7 +545,7 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
 // =============================================================================
 __global__ void k_build_image(const float *__restrict__ raw, const float *__restrict__ d_axis, float *__restrict__ img,
                               float *__restrict__ xq, long nslice, int ncol, double mu, double nu, int with_dop,
-                              int zero_pol, double mu_d, double alpha_d, double beta_d)
+                              int zero_pol, double mu_d, double alpha_d, double beta_d, double x_ref)
 {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = nslice * 1024 * ncol;
@@ -566,18 +566,19 @@ __global__ void k_build_image(const float *__restrict__ raw, const float *__rest
     }
     int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
     img[sl * 1024 * ncol + (((long)(q * 4 + k) * ncol + j) << 2) + s4] = val;
-    // exponent argument relative to the first diameter: k_prep folds exp(-lambda D_0^nu) into the unit's
-    // coefficient in float64, so the float32 sums keep their leading terms however large lambda is
-    if (sl == 0 && j == 0) xq[((q * 4 + k) << 2) + s4] = (float)(pow((double)D, nu) - pow((double)d_axis[0], nu));
+    // exponent argument relative to x_ref = the smallest D^nu of the axis (the first diameter of the reference's
+    // tables): k_prep folds exp(-lambda x_ref) into the unit's coefficient in float64, so the float32 sums keep
+    // their leading terms however large lambda is
+    if (sl == 0 && j == 0) xq[((q * 4 + k) << 2) + s4] = (float)(pow((double)D, nu) - x_ref);
 }
 
 void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                         int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
-                        double beta_d)
+                        double beta_d, double x_ref)
 {
     long total = nslice * 1024 * ncol;
     hipLaunchKernelGGL(k_build_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, d_axis, img, xq, nslice,
-                       ncol, mu, nu, with_dop, zero_pol, mu_d, alpha_d, beta_d);
+                       ncol, mu, nu, with_dop, zero_pol, mu_d, alpha_d, beta_d, x_ref);
 }
 
 // Compact image of the Doppler scheme-2 columns for units with a PSD of their own (k_integrate_dop):
@@ -587,7 +588,7 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 // sums keep their leading terms however large lambda is; the reference integrates in float64.
 __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__restrict__ d_axis,
                                   float *__restrict__ img, float *__restrict__ xq, long nslice, double mu_d, double nu_d,
-                                  double alpha_d, double beta_d)
+                                  double alpha_d, double beta_d, double x_ref)
 {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nslice * 1024) return;
@@ -598,7 +599,7 @@ __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__
     float rcs = (float)(2 * M_PI) * (((src[0] - src[1]) - src[2]) + src[3]);
     float xm = (float)pow((double)D, mu_d);
     float x = (float)pow((double)D, nu_d);
-    float x0 = (float)pow((double)d_axis[0], nu_d);
+    float x0 = (float)x_ref;                    // the smallest D^nu_d of the axis, as float32
     int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
     float *o = img + sl * CPOL_DOP_SLICE + (long)(q * 4 + k) * 12 + s4;
     o[0] = (float)((double)x - (double)x0);
@@ -608,11 +609,11 @@ __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__
 }
 
 void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
-                            double mu_d, double nu_d, double alpha_d, double beta_d)
+                            double mu_d, double nu_d, double alpha_d, double beta_d, double x_ref)
 {
     long total = nslice * 1024;
     hipLaunchKernelGGL(k_build_dop_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, d_axis, img, xq,
-                       nslice, mu_d, nu_d, alpha_d, beta_d);
+                       nslice, mu_d, nu_d, alpha_d, beta_d, x_ref);
 }
 
 // =============================================================================

@@ -113,6 +113,24 @@ def test_observables_with_extreme_contents(scheme, dscheme):
         util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
 
 
+def test_observables_with_descending_diameter_axis():
+    """A table whose diameter axis runs from large to small: no cutoff ordering applies (the library only uses it on
+    ascending axes) and the exponent reference is the smallest diameter wherever it sits; dD = D[1] - D[0] is
+    negative, as the reference would compute it (scattering_sz.py:50)."""
+    conf = O.make_config(microphysics={'scheme': 2}, attenuation={'correction': 0}, doppler={'scheme': 0},
+                         radar={'radial_resolution': 500., 'frequency': 5.6})
+    tabs = {h: (e, t, d[::-1].copy(), tab[:, :, ::-1, :].copy())
+            for h, (e, t, d, tab) in util.synthetic_lut_arrays(2, 5.6).items()}
+    eng = engine.Engine(conf, device=0)
+    eng.upload_luts({h: Lookup_table.from_arrays(*v) for h, v in tabs.items()})
+    beams = syn.synthetic_beams(150, 3, 2, seed=77, res=500.)
+    obs, mask, _ = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(beams), {h: O.Lut(*v) for h, v in tabs.items()}, conf)
+    check_obs(obs, want.values, 'descending axis', res_km=0.5)
+    np.testing.assert_array_equal(mask, want.mask)
+
+
 @pytest.mark.parametrize('ds', [1, 2, 3])
 def test_doppler_vs_golden(ds):
     """get_doppler_velocity (schemes 1, 2 and 3) against the reference's output."""
