@@ -69,6 +69,10 @@ class SimulatedRadar(object):
                 if k in table:
                     f[name] = table[k]
             self.fields[k] = f
+        if 'AH' in self.fields and 'AV' in self.fields and 'ADP' not in self.fields:
+            # convenience field, not in the reference's output: differential specific attenuation
+            adp = self.fields['AH']['data'] - self.fields['AV']['data']
+            self.fields['ADP'] = {'data': adp, 'long_name': 'Diff. specific attenuation', 'units': 'dB/km'}
         for k, v in (('Latitude', lat), ('Longitude', lon)):
             if v is not None:
                 self.fields[k] = {'data': np.ma.array(v, mask=np.isnan(v)), 'units': ['degrees']}

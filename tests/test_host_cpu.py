@@ -136,6 +136,7 @@ def _toy_radar(scan_type='ppi'):
     zh[0, 0] = 0.
     zh[1, 2] = np.nan
     fields = {'ZH': zh, 'ZDR': np.full_like(zh, 1.3), 'KDP': rng.normal(size=zh.shape).astype('float32'),
+              'AH': np.full_like(zh, 0.5), 'AV': np.full_like(zh, 0.125),
               'DSPECTRUM': rng.uniform(size=zh.shape + (4,))}
     lat = rng.uniform(45, 47, zh.shape)
     els = np.repeat([1.0, 2.5], n_ray) if scan_type == 'ppi' else np.tile([1., 2., 3.], n_sw)
@@ -156,6 +157,7 @@ def test_simulated_radar_fields():
     assert r.fields['ZH']['units'] == 'dBZ' and r.fields['ZH']['valid_max'] == 55
     assert r.fields['KDP']['long_name'] == 'Specific diff. phase'
     assert r.fields['DSPECTRUM']['data'].shape == (6, 5, 4)            # stays linear
+    np.testing.assert_array_equal(r.fields['ADP']['data'], 0.375)      # derived: AH - AV
     assert r.fields['range']['data'].shape == (6, 5) and r.fields['Latitude']['data'].shape == (6, 5)
     np.testing.assert_array_equal(r.fixed_angle['data'], [1.0, 2.5])
     np.testing.assert_array_equal(r.sweep_start_ray_index['data'], [0, 3])
