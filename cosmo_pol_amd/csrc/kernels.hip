@@ -265,7 +265,8 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     for (int l = 1; l <= 6; ++l) C1pa[l] = L[12 + l];
     for (int l = 1; l <= 5; ++l) C3a[l] = L[18 + l];
     double tau12 = (double)S / (bsemi * (1 + A1m1));
-    double s = sin(tau12), c = cos(tau12);
+    double s, c;
+    sincos(tau12, &s, &c);
     double B12 = -sin_cos_series(stau1 * c + ctau1 * s, ctau1 * c - stau1 * s, C1pa, 6);
     double sig12 = tau12 - (B12 - B11);
     // sin / cos of sig12 = tau12 + dlt from those of tau12: |dlt| < 3e-3 (series terms of order f), so five
@@ -294,7 +295,8 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     double dl = (lon - pollon) * DEG;
     // lat = atan2(sbet2, f1 cbet2): its sine and cosine are that pair normalised
     const double hphi = hypot(sbet2, f1 * cbet2);
-    double sphi = sbet2 / hphi, cphi = f1 * cbet2 / hphi, sdl = sin(dl), cdl = cos(dl);
+    double sphi = sbet2 / hphi, cphi = f1 * cbet2 / hphi, sdl, cdl;
+    sincos(dl, &sdl, &cdl);
     double a0 = cp * cphi * cdl + sp * sphi;
     double a1 = -sdl * cphi;
     double a2 = -sp * cphi * cdl + cp * sphi;
