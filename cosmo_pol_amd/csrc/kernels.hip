@@ -1472,7 +1472,7 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
 }
 
 // Stage 1, one thread per (ray, gate): sub-beam and class sums, observables without the range scans.
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 6)
 void k_gate_reduce(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
