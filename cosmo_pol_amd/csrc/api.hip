@@ -205,7 +205,7 @@ extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, c
                                  const float urc[2], const float res[2], const double pole[2])
 {
     if (!ctx || !var_ids || !data || !zlev || !llc || !urc || !res || !pole) return CPOL_ERR_ARG;
-    if (nvars < 1 || nvars > CPOL_MAX_VARS || nz < 3 || ny < 2 || nx < 2) return fail(ctx, CPOL_ERR_ARG, "bad model shape");
+    if (nvars < 1 || nvars > CPOL_V_COUNT || nz < 3 || ny < 2 || nx < 2) return fail(ctx, CPOL_ERR_ARG, "bad model shape");
     for (int i = 0; i < nvars; i++)
         if (var_ids[i] < 0 || var_ids[i] >= CPOL_V_COUNT || !data[i]) return fail(ctx, CPOL_ERR_ARG, "bad variable id");
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -354,7 +354,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     __shared__ int s_base[4][4][64];
     __shared__ float s_fz[4][4][64], s_hz[4][4][64], s_xy[4][4][64];
     __shared__ int s_code[4][64];
-    __shared__ float s_out[4][16][65];
+    __shared__ float s_out[4][CPOL_V_COUNT][65];      // one row per uploaded variable (at most CPOL_V_COUNT): five workgroups fit a CU
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = u < n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
