@@ -693,7 +693,7 @@ __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
     *len = end - hl;
 }
 
-__global__ void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
+__global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
                        const float *__restrict__ elev, const signed char *__restrict__ /*mask: invalid gates carry NaN*/,
                        const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
                        int *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
