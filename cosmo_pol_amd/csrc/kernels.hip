@@ -351,10 +351,13 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     // Phase B (wave-cooperative): the 2 x nv values of a neighbour column are contiguous in
     // memory, so 32 lanes fetch them with one coalesced access instead of 2 nv scattered ones.
     // Phase C: results go through LDS so that every variable plane is written 64 points at a time.
-    __shared__ int s_base[4][4][64];
-    __shared__ float s_fz[4][4][64], s_hz[4][4][64], s_xy[4][4][64];
-    __shared__ int s_code[4][64];
-    __shared__ float s_out[4][CPOL_V_COUNT][65];      // one row per uploaded variable (at most CPOL_V_COUNT): five workgroups fit a CU
+    // Exchange between the phases, one record of 17 words per point (odd stride: no bank conflicts):
+    //   [0..3] element offsets of the four level pairs, [4..7] level thicknesses, [8..11] heights above the lower
+    //   level, [12..15] x, y, 1-x, 1-y, [16] code.
+    // Phase B overwrites words 0..nv-1 of a point's record with its results once it has read the record (the
+    // lanes of a wave run in lockstep and a record is read only in the iteration that owns it, the offsets at
+    // the top of its group of eight), so the results need no area of their own: 17 KB per workgroup.
+    __shared__ float s_rec[4][64][17];
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = u < n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -463,8 +466,9 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
         }
     }
     if (mask && live) mask[u] = (signed char)code;
-    s_code[wv][lane] = code;
-    s_xy[wv][0][lane] = x; s_xy[wv][1][lane] = y; s_xy[wv][2][lane] = dx; s_xy[wv][3][lane] = dy;
+    float *rec = s_rec[wv][lane];
+    rec[16] = __int_as_float(code);
+    rec[12] = x; rec[13] = y; rec[14] = dx; rec[15] = dy;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         float fzj = 1.f, hzj = 0.f;
@@ -476,7 +480,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             hzj = H - zb;
             basej = (int)((cell[j] * nz + c1[j]) * nv);       // element offset of the level pair (< 2^31)
         }
-        s_base[wv][j][lane] = basej; s_fz[wv][j][lane] = fzj; s_hz[wv][j][lane] = hzj;
+        rec[j] = __int_as_float(basej); rec[4 + j] = fzj; rec[8 + j] = hzj;
     }
     __syncthreads();
     {
@@ -493,8 +497,9 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int pos = 2 * (p8 + i) + (lane >> 5);
-                const bool ok = s_code[wv][pos] == 0 && vact;
-                const int b0 = s_base[wv][c0][pos], b1 = s_base[wv][c1_][pos];
+                const float *pr = s_rec[wv][pos];
+                const bool ok = __float_as_int(pr[16]) == 0 && vact;
+                const int b0 = __float_as_int(pr[c0]), b1 = __float_as_int(pr[c1_]);
                 va[i][0] = ok ? dlane[b0] : 0.f; vb[i][0] = ok ? dlane[b0 + nv] : 0.f;
                 va[i][1] = ok ? dlane[b1] : 0.f; vb[i][1] = ok ? dlane[b1 + nv] : 0.f;
             }
@@ -503,11 +508,12 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
                 const int pos = 2 * (p8 + i) + (lane >> 5);
                 // nothing to do for a pair of points that both lie outside the model (the tail of a ray above
                 // the model top, the gates below the terrain): their outputs are sentinels
-                if (!__any(s_code[wv][pos] == 0)) continue;
+                float *pr = s_rec[wv][pos];
+                if (!__any(__float_as_int(pr[16]) == 0)) continue;
                 // vertical interpolation of the lane's two columns (interpolation_c.c:151)
-                const float w0 = vb[i][0] - (vb[i][0] - va[i][0]) / s_fz[wv][c0][pos] * s_hz[wv][c0][pos];
-                const float w1 = vb[i][1] - (vb[i][1] - va[i][1]) / s_fz[wv][c1_][pos] * s_hz[wv][c1_][pos];
-                const float px = s_xy[wv][0][pos], py = s_xy[wv][1][pos], pdx = s_xy[wv][2][pos], pdy = s_xy[wv][3][pos];
+                const float w0 = vb[i][0] - (vb[i][0] - va[i][0]) / pr[4 + c0] * pr[8 + c0];
+                const float w1 = vb[i][1] - (vb[i][1] - va[i][1]) / pr[4 + c1_] * pr[8 + c1_];
+                const float px = pr[12], py = pr[13], pdx = pr[14], pdy = pr[15];
                 // the four products of  dx*dy*v0 + x*v2*dy + dx*v1*y + x*y*v3  (:162), each in the reference's
                 // left-to-right order: columns 0, 1 in the lower half, columns 2, 3 in the upper half
                 const float ta = half ? (px * w0) * pdy : (pdx * pdy) * w0;      // t1 | t0
@@ -515,14 +521,14 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
                 const int s1 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, ta), 0x401f);
                 const int s3 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, tb), 0x401f);
                 const float o = ((ta + __builtin_bit_cast(float, s1)) + tb) + __builtin_bit_cast(float, s3);
-                if (half == 0 && vact) s_out[wv][v][pos] = o;
+                if (half == 0 && vact) pr[v] = o;          // the record has been read: its first words take the results
             }
         }
     }
     __syncthreads();
     if (live) {
         for (int v = 0; v < nv; v++) {
-            float o = s_out[wv][v][lane];
+            float o = s_rec[wv][lane][v];
             // raw_out keeps the reference's sentinels; vals gets NaN (interpolation.py:277)
             if (raw_out) raw_out[(long)v * n + u] = code == 0 ? o : (code < 0 ? -9999.f : qnan);
             if (vals) vals[(long)mv.var_of_slot[v] * plane + u] = code == 0 ? o : qnan;
