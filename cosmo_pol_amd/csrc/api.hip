@@ -399,7 +399,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         ct.lut_dop[h] = v;
         ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
-        // exponential per four diameters
+        // exponential per 64 diameters
         ct.pol_x0[h] = xref_of(L, L.psd.nu);
         ct.dop_x0[h] = (double)(float)xref_of(L, L.psd_dop.nu);
         // N(D) = 0 in float32 beyond a unit's cutoff needs D^nu ascending along the axis
@@ -408,7 +408,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         ct.cut_ok[h] = (asc && L.psd.nu > 0.) ? 1 : 0;
         ct.dop_cut_ok[h] = (asc && L.psd_dop.nu > 0.) ? 1 : 0;
         ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
-        ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
+        ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)L.axis_step : 0.f;
         fill_psd(ct.psd[h], L.psd);
         fill_psd(ct.dop[h], L.psd_dop);
         if (L.n_e > ct.ne_max) ct.ne_max = L.n_e;
@@ -522,10 +522,10 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
             d2.slice_floats = 1024 * 14;
             d2.at0[0] = 12 * 4; d2.at0[1] = 13 * 4;
             d2.at1[0] = (((63 * 4 + 3) * 14 + 12) << 2) + 3; d2.at1[1] = (((63 * 4 + 3) * 14 + 13) << 2) + 3;
-        } else {                   // words 1, 2 of the compact image
+        } else {                   // the moment pairs of the compact image follow its 1024 exponents
             d2.slice_floats = CPOL_DOP_SLICE;
-            d2.at0[0] = 4; d2.at0[1] = 8;
-            d2.at1[0] = (63 * 4 + 3) * 12 + 4 + 3; d2.at1[1] = (63 * 4 + 3) * 12 + 8 + 3;
+            d2.at0[0] = 1024; d2.at0[1] = 1025;
+            d2.at1[0] = 1024 + 2 * 1023; d2.at1[1] = 1025 + 2 * 1023;
         }
         for (int h = 0; h < ct.n_cls; h++) {
             const LutView &v = ct.dop_shared ? ct.lut[h] : ct.lut_dop[h];

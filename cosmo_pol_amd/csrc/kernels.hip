@@ -590,8 +590,8 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 }
 
 // Compact image of the Doppler scheme-2 columns for units with a PSD of their own (k_integrate_dop):
-//   img[sl][w = 4 q + k][c][s],  d = 16 q + 4 s + k,  c = 0: D^nu_d - D_0^nu_d,  1: rcs D^mu_d,  2: rcs v(D) D^mu_d
-// i.e. 12 KB per (e, t) node, three 16-byte words per group of four diameters.  The exponent is taken
+//   img[sl][d] = D^nu_d - D_0^nu_d  (d < 1024),   img[sl][1024 + 2 d + c] = rcs D^mu_d (c = 0), rcs v(D) D^mu_d (c = 1)
+// i.e. 12 KB per (e, t) node; the two moments of a diameter sit side by side for packed arithmetic.  The exponent is taken
 // relative to the first diameter (k_prep folds exp(-lambda D_0^nu) into the unit's N0), so that the float32
 // sums keep their leading terms however large lambda is; the reference integrates in float64.
 __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__restrict__ d_axis,
@@ -608,12 +608,11 @@ __global__ void k_build_dop_image(const float *__restrict__ raw, const float *__
     float xm = (float)pow((double)D, mu_d);
     float x = (float)pow((double)D, nu_d);
     float x0 = (float)x_ref;                    // the smallest D^nu_d of the axis, as float32
-    int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
-    float *o = img + sl * CPOL_DOP_SLICE + (long)(q * 4 + k) * 12 + s4;
-    o[0] = (float)((double)x - (double)x0);
-    o[4] = rcs * xm;
-    o[8] = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * xm;
-    if (sl == 0) xq[((q * 4 + k) << 2) + s4] = x;
+    float *o = img + sl * CPOL_DOP_SLICE;
+    o[d] = (float)((double)x - (double)x0);
+    o[1024 + 2 * d] = rcs * xm;
+    o[1024 + 2 * d + 1] = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * xm;
+    if (sl == 0) xq[d] = x;
 }
 
 void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
@@ -1208,30 +1207,22 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
 // =============================================================================
 #define DOP_THREADS (CPOL_CHUNK_UNITS / 2)      // two units per lane: every LDS word read serves both
 
-// plain path of one unit: one exponential per diameter, over the first nq8 quads (a multiple of 8)
+// plain path of one unit: one exponential per diameter, over the first nq8 quads (a multiple of 8); the two
+// moments of a diameter are accumulated as one packed pair
 __device__ inline void dop_unit_plain(const float *lds, float2 l, int nq8, double *o12, double *o13)
 {
-    const float4 *I4 = (const float4 *)lds;
-    const f32x2 nhi = {-l.x, -l.x}, nlo = {-l.y, -l.y};
+    const f32x2 *BB = (const f32x2 *)(lds + 1024);
     double s12 = 0., s13 = 0.;
-    for (int wo = 0; wo < 4 * nq8; wo += 32) {
-        f32x2 a12 = {0.f, 0.f}, a13 = {0.f, 0.f};
-#pragma unroll 4
-        for (int w = wo; w < wo + 32; w++) {
-            const float4 x = I4[3 * w], b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
-            const f32x2 x01 = {x.x, x.y}, x23 = {x.z, x.w};
-            const f32x2 p01 = __builtin_elementwise_fma(nhi, x01, nlo * x01);
-            const f32x2 p23 = __builtin_elementwise_fma(nhi, x23, nlo * x23);
-            const f32x2 n01 = {__builtin_amdgcn_exp2f(p01.x), __builtin_amdgcn_exp2f(p01.y)};
-            const f32x2 n23 = {__builtin_amdgcn_exp2f(p23.x), __builtin_amdgcn_exp2f(p23.y)};
-            const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
-            a12 = __builtin_elementwise_fma(n01, u01, a12);
-            a13 = __builtin_elementwise_fma(n01, v01, a13);
-            a12 = __builtin_elementwise_fma(n23, u23, a12);
-            a13 = __builtin_elementwise_fma(n23, v23, a13);
+    for (int d0 = 0; d0 < 16 * nq8; d0 += 128) {
+        f32x2 a = {0.f, 0.f};
+#pragma unroll 8
+        for (int d = d0; d < d0 + 128; d++) {
+            const float x = lds[d];
+            const float n = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x, -l.y * x));
+            a = __builtin_elementwise_fma((f32x2){n, n}, BB[d], a);
         }
-        s12 += (double)a12.x + (double)a12.y;
-        s13 += (double)a13.x + (double)a13.y;
+        s12 += (double)a.x;
+        s13 += (double)a.y;
     }
     *o12 = s12; *o13 = s13;
 }
@@ -1293,7 +1284,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
                 int c = 0;
 #pragma unroll
                 for (int step = 64; step >= 1; step >>= 1)
-                    if (c + step <= 64 && lds[12 * 4 * (c + step - 1)] <= xc) c += step;     // first D^nu - D_0^nu of a quad
+                    if (c + step <= 64 && lds[16 * (c + step - 1)] <= xc) c += step;     // first D^nu - D_0^nu of a quad
                 nqu[t] = c;
             }
             myrank[t] = atomicAdd(&s_hist[nqu[t]], 1);
@@ -1335,73 +1326,67 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
             if (have[t]) dop_out[(long)slot[t] - slot0] = make_float2(0.f, 0.f);
         return;
     }
-    const float4 *I4 = (const float4 *)lds;
+    const f32x4 *BB4 = (const f32x4 *)(lds + 1024);      // word j of quad q: the moment pairs of diameters 16 q + 2 j, + 1
     double s12[2] = {0., 0.}, s13[2] = {0., 0.};
-    const float gstep = ct.dop_geo_step[h];
+    const float gstep = ct.dop_geo_step[h];      // diameter step when N(D) is geometric, else 0
     if (gstep > 0.f) {
-        // nu = 1 on a uniform axis: N(D) is a geometric sequence.  The four diameters of a word are 4 steps
-        // apart (ratio R), the same word of the next quad is 16 steps further (ratio R^4): one exponential seeds
-        // four quads of one word position, i.e. 16 diameters; at most five roundings separate a value from its seed
-        float R[2];
-        f32x2 R2[2], R4[2];
+        // nu = 1 on a uniform axis: N(D_0 + i step) = N(D_0) R^i, so a quad's sum over 16 diameters is N(quad start)
+        // times the polynomial sum_i B_i R^i, evaluated by Horner's rule on the packed pair of moments: one packed
+        // FMA per diameter and unit.  N(quad start) comes from an exponential every fourth quad and R^16 in between.
+        f32x2 Rv[2];
+        float R16[2];
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            R[t] = __builtin_amdgcn_exp2f(-(l[t].x * gstep + l[t].y * gstep));
-            const float rs = R[t] * R[t];
-            R2[t] = (f32x2){rs, rs};
-            R4[t] = R2[t] * R2[t];
+            const float arg = l[t].x * gstep + l[t].y * gstep;
+            const float R = __builtin_amdgcn_exp2f(-arg);
+            Rv[t] = (f32x2){R, R};
+            R16[t] = __builtin_amdgcn_exp2f(-16.f * arg);
         }
         for (int qo = 0; qo < nq8; qo += 8) {
-            f32x2 a12[2] = {{0.f, 0.f}, {0.f, 0.f}}, a13[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            f32x2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int q4 = 0; q4 < 8; q4 += 4) {
+                const float xs0 = lds[16 * (qo + q4)];
+                float nq_[2];
 #pragma unroll
-                for (int hq = 0; hq < 8; hq += 4) {
-                    const int w0 = 4 * (qo + hq) + k;
-                    const float x0 = lds[12 * w0];
-                    f32x2 n01[2], n23[2];
+                for (int t = 0; t < 2; t++) nq_[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, xs0, -l[t].y * xs0));
 #pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, x0, -l[t].y * x0));
-                        n01[t] = (f32x2){n0, n0 * R[t]};
-                        n23[t] = n01[t] * R2[t];
-                    }
+                for (int m = 0; m < 4; m++) {
+                    const f32x4 *w = BB4 + 8 * (qo + q4 + m);
+                    f32x2 S[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const int w = w0 + 4 * m;
-                        const float4 b12 = I4[3 * w + 1], b13 = I4[3 * w + 2];
-                        const f32x2 u01 = {b12.x, b12.y}, u23 = {b12.z, b12.w}, v01 = {b13.x, b13.y}, v23 = {b13.z, b13.w};
+                    for (int j = 7; j >= 0; j--) {
+                        const f32x4 b = w[j];
+                        const f32x2 hi = {b.z, b.w}, lo = {b.x, b.y};
 #pragma unroll
                         for (int t = 0; t < 2; t++) {
-                            a12[t] = __builtin_elementwise_fma(n01[t], u01, a12[t]);
-                            a13[t] = __builtin_elementwise_fma(n01[t], v01, a13[t]);
-                            a12[t] = __builtin_elementwise_fma(n23[t], u23, a12[t]);
-                            a13[t] = __builtin_elementwise_fma(n23[t], v23, a13[t]);
-                            if (m < 3) { n01[t] = n01[t] * R4[t]; n23[t] = n23[t] * R4[t]; }
+                            S[t] = __builtin_elementwise_fma(S[t], Rv[t], hi);
+                            S[t] = __builtin_elementwise_fma(S[t], Rv[t], lo);
                         }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        acc[t] = __builtin_elementwise_fma((f32x2){nq_[t], nq_[t]}, S[t], acc[t]);
+                        nq_[t] *= R16[t];
                     }
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                s12[t] += (double)a12[t].x + (double)a12[t].y;
-                s13[t] += (double)a13[t].x + (double)a13[t].y;
-            }
+            for (int t = 0; t < 2; t++) { s12[t] += (double)acc[t].x; s13[t] += (double)acc[t].y; }
         }
     } else {
         for (int t = 0; t < 2; t++)
             if (have[t]) dop_unit_plain(lds, l[t], nq8, &s12[t], &s13[t]);
     }
     // unit-spacing trapezoid rule (doppler_sz.py:219-220): the sum minus half of the two end terms
-    const int wl = 12 * 255 + 3;                 // d = 1023 is the last element of the last word
-    const float x0 = lds[0], xl = lds[wl];
+    const float x0 = lds[0], xl = lds[1023];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         if (!have[t]) continue;
         const float na = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, x0, -l[t].y * x0));
         const float nz = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, xl, -l[t].y * xl));
-        const double r12 = s12[t] - 0.5 * ((double)na * (double)lds[4] + (double)nz * (double)lds[wl + 4]);
-        const double r13 = s13[t] - 0.5 * ((double)na * (double)lds[8] + (double)nz * (double)lds[wl + 8]);
+        const double r12 = s12[t] - 0.5 * ((double)na * (double)lds[1024] + (double)nz * (double)lds[1024 + 2 * 1023]);
+        const double r13 = s13[t] - 0.5 * ((double)na * (double)lds[1025] + (double)nz * (double)lds[1025 + 2 * 1023]);
         dop_out[(long)slot[t] - slot0] = make_float2((float)r12, (float)r13);     // indexed like the polarimetric twin
     }
 }
