@@ -215,14 +215,18 @@ extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, c
     if (ctx->dcol) { HIPCHK(ctx, hipFree(ctx->dcol)); ctx->dcol = nullptr; }
     ctx->have_model = false;
     HIPCHK(ctx, hipMalloc((void **)&ctx->zcol, nvox * sizeof(float)));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->dcol, nvox * nvars * sizeof(float)));
+    // a level's variables are padded to whole 16-byte words (k_interp reads them as such and keeps 32-bit word offsets)
+    const int nvp = (nvars + 3) & ~3;
+    if ((double)nvox * (nvp / 4) >= 2147483648.) return fail(ctx, CPOL_ERR_ARG, "model too large: nz*ny*nx*ceil(nvars/4) must stay below 2^31");
+    HIPCHK(ctx, hipMalloc((void **)&ctx->dcol, nvox * nvp * sizeof(float)));
+    if (nvp != nvars) HIPCHK(ctx, hipMemsetAsync(ctx->dcol, 0, nvox * nvp * sizeof(float), ctx->stream));
     TRY(ensure(ctx, ctx->b_stage, nvox * sizeof(float)));
     float *stage = (float *)ctx->b_stage.p;
     HIPCHK(ctx, hipMemcpyAsync(stage, zlev, nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
     launch_transpose_levels(ctx->stream, stage, ctx->zcol, nz, ncell, 1, 0);
     for (int i = 0; i < nvars; i++) {
         HIPCHK(ctx, hipMemcpyAsync(stage, data[i], nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
-        launch_transpose_levels(ctx->stream, stage, ctx->dcol, nz, ncell, nvars, i);
+        launch_transpose_levels(ctx->stream, stage, ctx->dcol, nz, ncell, nvp, i);
         ctx->var_ids[i] = var_ids[i];
     }
     HIPCHK(ctx, hipGetLastError());
@@ -441,7 +445,7 @@ static void build_model_view(const cpol_ctx *ctx, ModelView &mv)
 {
     memset(&mv, 0, sizeof(mv));
     mv.zcol = ctx->zcol; mv.dcol = ctx->dcol;
-    mv.nz = ctx->nz; mv.ny = ctx->ny; mv.nx = ctx->nx; mv.nv = ctx->nv;
+    mv.nz = ctx->nz; mv.ny = ctx->ny; mv.nx = ctx->nx; mv.nv = ctx->nv; mv.nvp = (ctx->nv + 3) & ~3;
     mv.llc0 = ctx->llc[0]; mv.llc1 = ctx->llc[1]; mv.res0 = ctx->res[0]; mv.res1 = ctx->res[1];
     mv.urc0 = ctx->urc[0]; mv.urc1 = ctx->urc[1];
     for (int i = 0; i < ctx->nv; i++) mv.var_of_slot[i] = ctx->var_ids[i];

@@ -70,8 +70,8 @@ struct ClassTable {
 
 struct ModelView {
     const float *zcol;             // [ny][nx][nz]     heights, level index fastest
-    const float *dcol;             // [ny][nx][nz][nv] variables interleaved per level
-    int   nz, ny, nx, nv;
+    const float *dcol;             // [ny][nx][nz][nvp] variables interleaved per level, nvp = nv rounded up to 4
+    int   nz, ny, nx, nv, nvp;
     float llc0, llc1, res0, res1;  // (Lo1, La1), (dlon, dlat)
     float urc0, urc1;
     int   var_of_slot[CPOL_MAX_VARS];   // uploaded variable i -> cpol_var slot

@@ -343,22 +343,37 @@ __device__ inline int level_search(const float *__restrict__ col, int dim, float
     return high;
 }
 
+#define INTERP_XCD_RUN 72
+#define INTERP_REC 19
 __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords, const float *__restrict__ Hh,
                          float *__restrict__ vals, long plane, signed char *__restrict__ mask,
                          float *__restrict__ raw_out)
 {
     // Phase A (one thread per point): grid position, terrain test, level search.
-    // Phase B (wave-cooperative): the 2 x nv values of a neighbour column are contiguous in
-    // memory, so 32 lanes fetch them with one coalesced access instead of 2 nv scattered ones.
+    // Phase B (wave-cooperative): the 2 x nvp values of a neighbour column are contiguous in memory, so
+    // sixteen lanes fetch a point's four columns with 16-byte loads instead of 8 nv scattered ones.
     // Phase C: results go through LDS so that every variable plane is written 64 points at a time.
-    // Exchange between the phases, one record of 17 words per point (odd stride: no bank conflicts):
+    // Exchange between the phases, one record of 19 words per point (odd stride: no bank conflicts):
     //   [0..3] element offsets of the four level pairs, [4..7] level thicknesses, [8..11] heights above the lower
-    //   level, [12..15] x, y, 1-x, 1-y, [16] code.
+    //   level, [12..15] reciprocals of the thicknesses, [16] x, [17] y, [18] code (0 ok, 2 ok but divide the long way).
     // Phase B overwrites words 0..nv-1 of a point's record with its results once it has read the record (the
     // lanes of a wave run in lockstep and a record is read only in the iteration that owns it, the offsets at
-    // the top of its group of eight), so the results need no area of their own: 17 KB per workgroup.
-    __shared__ float s_rec[4][64][17];
-    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // the top of its group of eight), so the results need no area of their own: 19 KB per workgroup.
+    //
+    // The division (vb - va) / thickness of interpolation_c.c:151 has the same divisor for every variable of a
+    // column.  The correctly rounded quotient is the compiler's own sequence: a reciprocal refined by one Newton
+    // step, then q = a r and two residual corrections q += (a - q d) r.  The reciprocal is computed once per
+    // point and column in phase A; phase B keeps the five instructions that depend on the numerator.  That
+    // sequence rescales its operands when the numerator is tiny or the quotient could leave the normal range;
+    // such wave iterations (and thicknesses outside 2^-20 .. 2^20) take the plain division instead, so the result
+    // is the IEEE quotient in every case.
+    __shared__ float s_rec[4][64][INTERP_REC];
+    // Workgroups are dealt to the eight XCDs in turn, each XCD with an L2 of its own.  Neighbouring sub-beams and
+    // rays read the same model columns, so an XCD takes runs of INTERP_XCD_RUN consecutive blocks (about four
+    // rays of nine sub-beams); short runs keep the XCDs evenly loaded although high elevations leave the model early.
+    const long kx = blockIdx.x >> 3;
+    const long bid = ((kx / INTERP_XCD_RUN) * 8 + (blockIdx.x & 7)) * INTERP_XCD_RUN + kx % INTERP_XCD_RUN;
+    long u = bid * blockDim.x + threadIdx.x;
     const bool live = u < n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float qnan = __builtin_nanf("");
@@ -467,8 +482,8 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     }
     if (mask && live) mask[u] = (signed char)code;
     float *rec = s_rec[wv][lane];
-    rec[16] = __int_as_float(code);
-    rec[12] = x; rec[13] = y; rec[14] = dx; rec[15] = dy;
+    rec[16] = x; rec[17] = y;
+    bool long_div = false;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         float fzj = 1.f, hzj = 0.f;
@@ -478,50 +493,83 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             float za = zc[0], zb = zc[1];
             fzj = za - zb;
             hzj = H - zb;
-            basej = (int)((cell[j] * nz + c1[j]) * nv);       // element offset of the level pair (< 2^31)
+            basej = (int)((cell[j] * nz + c1[j]) * (mv.nvp >> 2));    // offset of the level pair in 16-byte words (< 2^31)
         }
-        rec[j] = __int_as_float(basej); rec[4 + j] = fzj; rec[8 + j] = hzj;
+        const float r0 = __builtin_amdgcn_rcpf(fzj);
+        const float rj = __builtin_fmaf(__builtin_fmaf(-fzj, r0, 1.f), r0, r0);
+        long_div = long_div || !(fabsf(fzj) >= 0x1p-20f && fabsf(fzj) <= 0x1p20f);
+        rec[j] = __int_as_float(basej); rec[4 + j] = fzj; rec[8 + j] = hzj; rec[12 + j] = rj;
     }
+    rec[18] = __int_as_float(code == 0 && long_div ? 2 : code);
     __syncthreads();
     {
-        // 32 lanes per point: lanes 0-15 take neighbour columns 0 and 1, lanes 16-31 columns 2 and 3; lane v of a
-        // half handles variable v.  A column's two levels are 2 nv contiguous floats, so every load instruction
-        // reads runs of nv consecutive floats.
-        const int sl = lane & 31, v = sl & 15, half = sl >> 4;
-        const bool vact = v < nv;
-        const float *dlane = mv.dcol + v;
-        const int c0 = 2 * half, c1_ = 2 * half + 1;
-        for (int p8 = 0; p8 < 32; p8 += 8) {
-            // issue the 32 loads of eight point pairs before using any of them
-            float va[8][2], vb[8][2];
+        // 16 lanes per point: lane (j, k) of a point's group takes neighbour column j and the four variables
+        // 4k .. 4k+3.  A level of a column is nvp (a multiple of four) consecutive floats, so a lane fetches its
+        // variables of the two levels with two 16-byte loads and a column's level pair is read as two runs of
+        // 4 nvp bytes; one wave instruction serves four points.
+        const int grp = lane >> 4, j = (lane >> 2) & 3, k = lane & 3;
+        const int nq = mv.nvp >> 2;
+        const bool kact = k < nq;
+        const float4 *dlane = (const float4 *)mv.dcol + (kact ? k : 0);
+        for (int p4 = 0; p4 < 16; p4 += 4) {
+            // issue the loads of four groups of four points before using any of them
+            float4 va[4], vb[4];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int pos = 2 * (p8 + i) + (lane >> 5);
-                const float *pr = s_rec[wv][pos];
-                const bool ok = __float_as_int(pr[16]) == 0 && vact;
-                const int b0 = __float_as_int(pr[c0]), b1 = __float_as_int(pr[c1_]);
-                va[i][0] = ok ? dlane[b0] : 0.f; vb[i][0] = ok ? dlane[b0 + nv] : 0.f;
-                va[i][1] = ok ? dlane[b1] : 0.f; vb[i][1] = ok ? dlane[b1 + nv] : 0.f;
+            for (int i = 0; i < 4; i++) {
+                const float *pr = s_rec[wv][4 * (p4 + i) + grp];
+                // a point outside the model reads the first column instead: its results are never used
+                const int b = (__float_as_int(pr[18]) & ~2) == 0 ? __float_as_int(pr[j]) : 0;
+                va[i] = dlane[b];
+                vb[i] = dlane[b + nq];
             }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int pos = 2 * (p8 + i) + (lane >> 5);
-                // nothing to do for a pair of points that both lie outside the model (the tail of a ray above
-                // the model top, the gates below the terrain): their outputs are sentinels
-                float *pr = s_rec[wv][pos];
-                if (!__any(__float_as_int(pr[16]) == 0)) continue;
-                // vertical interpolation of the lane's two columns (interpolation_c.c:151)
-                const float w0 = vb[i][0] - (vb[i][0] - va[i][0]) / pr[4 + c0] * pr[8 + c0];
-                const float w1 = vb[i][1] - (vb[i][1] - va[i][1]) / pr[4 + c1_] * pr[8 + c1_];
-                const float px = pr[12], py = pr[13], pdx = pr[14], pdy = pr[15];
-                // the four products of  dx*dy*v0 + x*v2*dy + dx*v1*y + x*y*v3  (:162), each in the reference's
-                // left-to-right order: columns 0, 1 in the lower half, columns 2, 3 in the upper half
-                const float ta = half ? (px * w0) * pdy : (pdx * pdy) * w0;      // t1 | t0
-                const float tb = half ? (px * py) * w1 : (pdx * w1) * py;        // t3 | t2
-                const int s1 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, ta), 0x401f);
-                const int s3 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, tb), 0x401f);
-                const float o = ((ta + __builtin_bit_cast(float, s1)) + tb) + __builtin_bit_cast(float, s3);
-                if (half == 0 && vact) pr[v] = o;          // the record has been read: its first words take the results
+            for (int i = 0; i < 4; i++) {
+                // nothing to do for four points that all lie outside the model (the tail of a ray above the model
+                // top, the gates below the terrain): their outputs are sentinels
+                float *pr = s_rec[wv][4 * (p4 + i) + grp];
+                const int pcode = __float_as_int(pr[18]);
+                if (!__any((pcode & ~2) == 0)) continue;
+                const float d = pr[4 + j], hz = pr[8 + j], r = pr[12 + j];
+                const float px = pr[16], py = pr[17], pdx = 1.0f - px, pdy = 1.0f - py;
+                const float A[4] = {va[i].x, va[i].y, va[i].z, va[i].w}, B[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+                float a[4], q[4];
+                bool short_ok = pcode != 2;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    a[c] = B[c] - A[c];
+                    const float m = fabsf(a[c]);
+                    short_ok = short_ok && (a[c] == 0.f || (m >= 0x1p-90f && m < 0x1p100f));
+                }
+                if (__all(short_ok || (pcode & ~2) != 0)) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float t = a[c] * r;
+                        t = __builtin_fmaf(__builtin_fmaf(-d, t, a[c]), r, t);
+                        q[c] = __builtin_fmaf(__builtin_fmaf(-d, t, a[c]), r, t);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) q[c] = a[c] / d;
+                }
+                // the column's product of  dx*dy*v0 + x*v2*dy + dx*v1*y + x*y*v3  (interpolation_c.c:162) in the
+                // reference's left-to-right order, written (f w) g with g = 1 where the weights come first
+                const float f = j == 0 ? pdx * pdy : j == 1 ? pdx : j == 2 ? px : px * py;
+                const float g = j == 1 ? py : j == 2 ? pdy : 1.0f;
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float w = B[c] - q[c] * hz;                  // vertical interpolation (:151)
+                    const float t = (f * w) * g;
+                    // lanes of column 0 collect ((t0 + t2) + t1) + t3: columns 2, 1, 3 sit 8, 4, 12 lanes up
+                    const int s2 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x201f);
+                    const int s1 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x101f);
+                    const int s3 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x301f);
+                    o[c] = ((t + __builtin_bit_cast(float, s2)) + __builtin_bit_cast(float, s1)) + __builtin_bit_cast(float, s3);
+                }
+                if (j == 0 && kact) {          // the record has been read: its first words take the results
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pr[4 * k + c] = o[c];
+                }
             }
         }
     }
@@ -539,7 +587,9 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
 void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coords, const float *H,
                    float *vals, long plane, signed char *mask, float *raw_out)
 {
-    hipLaunchKernelGGL(k_interp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mv, n, coords, H, vals,
+    const long nb = (n + 255) / 256;
+    const long per = 8L * INTERP_XCD_RUN;
+    hipLaunchKernelGGL(k_interp, dim3((unsigned)((nb + per - 1) / per * per)), dim3(256), 0, s, mv, n, coords, H, vals,
                        plane, mask, raw_out);
 }
 
