@@ -344,7 +344,7 @@ __device__ inline int level_search(const float *__restrict__ col, int dim, float
 }
 
 #define INTERP_XCD_RUN 72
-#define INTERP_REC 19
+#define INTERP_REC 17
 __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords, const float *__restrict__ Hh,
                          float *__restrict__ vals, long plane, signed char *__restrict__ mask,
                          float *__restrict__ raw_out)
@@ -353,20 +353,12 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     // Phase B (wave-cooperative): the 2 x nvp values of a neighbour column are contiguous in memory, so
     // sixteen lanes fetch a point's four columns with 16-byte loads instead of 8 nv scattered ones.
     // Phase C: results go through LDS so that every variable plane is written 64 points at a time.
-    // Exchange between the phases, one record of 19 words per point (odd stride: no bank conflicts):
-    //   [0..3] element offsets of the four level pairs, [4..7] level thicknesses, [8..11] heights above the lower
-    //   level, [12..15] reciprocals of the thicknesses, [16] x, [17] y, [18] code (0 ok, 2 ok but divide the long way).
-    // Phase B overwrites words 0..nv-1 of a point's record with its results once it has read the record (the
+    // Exchange between the phases, one record of 17 words per point (odd stride: no bank conflicts):
+    //   [0..3] offsets of the four level pairs, [4..7] level thicknesses, [8..11] heights above the lower
+    //   level, [12] x, [13] y, [14] code.
+    // Phase B overwrites words 0..nvp-1 of a point's record with its results once it has read the record (the
     // lanes of a wave run in lockstep and a record is read only in the iteration that owns it, the offsets at
-    // the top of its group of eight), so the results need no area of their own: 19 KB per workgroup.
-    //
-    // The division (vb - va) / thickness of interpolation_c.c:151 has the same divisor for every variable of a
-    // column.  The correctly rounded quotient is the compiler's own sequence: a reciprocal refined by one Newton
-    // step, then q = a r and two residual corrections q += (a - q d) r.  The reciprocal is computed once per
-    // point and column in phase A; phase B keeps the five instructions that depend on the numerator.  That
-    // sequence rescales its operands when the numerator is tiny or the quotient could leave the normal range;
-    // such wave iterations (and thicknesses outside 2^-20 .. 2^20) take the plain division instead, so the result
-    // is the IEEE quotient in every case.
+    // the top of its group of four), so the results need no area of their own: 17 KB per workgroup.
     __shared__ float s_rec[4][64][INTERP_REC];
     // Workgroups are dealt to the eight XCDs in turn, each XCD with an L2 of its own.  Neighbouring sub-beams and
     // rays read the same model columns, so an XCD takes runs of INTERP_XCD_RUN consecutive blocks (about four
@@ -482,8 +474,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     }
     if (mask && live) mask[u] = (signed char)code;
     float *rec = s_rec[wv][lane];
-    rec[16] = x; rec[17] = y;
-    bool long_div = false;
+    rec[12] = x; rec[13] = y; rec[14] = __int_as_float(code);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         float fzj = 1.f, hzj = 0.f;
@@ -495,12 +486,8 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             hzj = H - zb;
             basej = (int)((cell[j] * nz + c1[j]) * (mv.nvp >> 2));    // offset of the level pair in 16-byte words (< 2^31)
         }
-        const float r0 = __builtin_amdgcn_rcpf(fzj);
-        const float rj = __builtin_fmaf(__builtin_fmaf(-fzj, r0, 1.f), r0, r0);
-        long_div = long_div || !(fabsf(fzj) >= 0x1p-20f && fabsf(fzj) <= 0x1p20f);
-        rec[j] = __int_as_float(basej); rec[4 + j] = fzj; rec[8 + j] = hzj; rec[12 + j] = rj;
+        rec[j] = __int_as_float(basej); rec[4 + j] = fzj; rec[8 + j] = hzj;
     }
-    rec[18] = __int_as_float(code == 0 && long_div ? 2 : code);
     __syncthreads();
     {
         // 16 lanes per point: lane (j, k) of a point's group takes neighbour column j and the four variables
@@ -518,7 +505,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             for (int i = 0; i < 4; i++) {
                 const float *pr = s_rec[wv][4 * (p4 + i) + grp];
                 // a point outside the model reads the first column instead: its results are never used
-                const int b = (__float_as_int(pr[18]) & ~2) == 0 ? __float_as_int(pr[j]) : 0;
+                const int b = __float_as_int(pr[14]) == 0 ? __float_as_int(pr[j]) : 0;
                 va[i] = dlane[b];
                 vb[i] = dlane[b + nq];
             }
@@ -527,30 +514,10 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
                 // nothing to do for four points that all lie outside the model (the tail of a ray above the model
                 // top, the gates below the terrain): their outputs are sentinels
                 float *pr = s_rec[wv][4 * (p4 + i) + grp];
-                const int pcode = __float_as_int(pr[18]);
-                if (!__any((pcode & ~2) == 0)) continue;
-                const float d = pr[4 + j], hz = pr[8 + j], r = pr[12 + j];
-                const float px = pr[16], py = pr[17], pdx = 1.0f - px, pdy = 1.0f - py;
+                if (!__any(__float_as_int(pr[14]) == 0)) continue;
+                const float d = pr[4 + j], hz = pr[8 + j];
+                const float px = pr[12], py = pr[13], pdx = 1.0f - px, pdy = 1.0f - py;
                 const float A[4] = {va[i].x, va[i].y, va[i].z, va[i].w}, B[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
-                float a[4], q[4];
-                bool short_ok = pcode != 2;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    a[c] = B[c] - A[c];
-                    const float m = fabsf(a[c]);
-                    short_ok = short_ok && (a[c] == 0.f || (m >= 0x1p-90f && m < 0x1p100f));
-                }
-                if (__all(short_ok || (pcode & ~2) != 0)) {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        float t = a[c] * r;
-                        t = __builtin_fmaf(__builtin_fmaf(-d, t, a[c]), r, t);
-                        q[c] = __builtin_fmaf(__builtin_fmaf(-d, t, a[c]), r, t);
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) q[c] = a[c] / d;
-                }
                 // the column's product of  dx*dy*v0 + x*v2*dy + dx*v1*y + x*y*v3  (interpolation_c.c:162) in the
                 // reference's left-to-right order, written (f w) g with g = 1 where the weights come first
                 const float f = j == 0 ? pdx * pdy : j == 1 ? pdx : j == 2 ? px : px * py;
@@ -558,7 +525,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
                 float o[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float w = B[c] - q[c] * hz;                  // vertical interpolation (:151)
+                    const float w = B[c] - (B[c] - A[c]) / d * hz;     // vertical interpolation (:151)
                     const float t = (f * w) * g;
                     // lanes of column 0 collect ((t0 + t2) + t1) + t3: columns 2, 1, 3 sit 8, 4, 12 lanes up
                     const int s2 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x201f);
