@@ -150,6 +150,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto *b : ctx->bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->zcol) (void)hipFree(ctx->zcol);
+    if (ctx->zc8) (void)hipFree(ctx->zc8);
     if (ctx->dcol) (void)hipFree(ctx->dcol);
     if (ctx->quad_dev) (void)hipFree(ctx->quad_dev);
     if (ctx->varray_dev) (void)hipFree(ctx->varray_dev);
@@ -212,9 +213,11 @@ extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, c
     long ncell = (long)ny * nx;
     size_t nvox = (size_t)ncell * nz;
     if (ctx->zcol) { HIPCHK(ctx, hipFree(ctx->zcol)); ctx->zcol = nullptr; }
+    if (ctx->zc8) { HIPCHK(ctx, hipFree(ctx->zc8)); ctx->zc8 = nullptr; }
     if (ctx->dcol) { HIPCHK(ctx, hipFree(ctx->dcol)); ctx->dcol = nullptr; }
     ctx->have_model = false;
     HIPCHK(ctx, hipMalloc((void **)&ctx->zcol, nvox * sizeof(float)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->zc8, (size_t)ncell * 8 * sizeof(float)));
     // a level's variables are padded to whole 16-byte words (k_interp reads them as such and keeps 32-bit word offsets)
     const int nvp = (nvars + 3) & ~3;
     if ((double)nvox * (nvp / 4) >= 2147483648.) return fail(ctx, CPOL_ERR_ARG, "model too large: nz*ny*nx*ceil(nvars/4) must stay below 2^31");
@@ -224,6 +227,7 @@ extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, c
     float *stage = (float *)ctx->b_stage.p;
     HIPCHK(ctx, hipMemcpyAsync(stage, zlev, nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
     launch_transpose_levels(ctx->stream, stage, ctx->zcol, nz, ncell, 1, 0);
+    launch_coarse_levels(ctx->stream, ctx->zcol, ctx->zc8, nz, ncell);
     for (int i = 0; i < nvars; i++) {
         HIPCHK(ctx, hipMemcpyAsync(stage, data[i], nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
         launch_transpose_levels(ctx->stream, stage, ctx->dcol, nz, ncell, nvp, i);
@@ -444,7 +448,7 @@ static void build_obs_params(const cpol_ctx *ctx, int n_sub, int n_gates, int n_
 static void build_model_view(const cpol_ctx *ctx, ModelView &mv)
 {
     memset(&mv, 0, sizeof(mv));
-    mv.zcol = ctx->zcol; mv.dcol = ctx->dcol;
+    mv.zcol = ctx->zcol; mv.zc8 = ctx->zc8; mv.dcol = ctx->dcol;
     mv.nz = ctx->nz; mv.ny = ctx->ny; mv.nx = ctx->nx; mv.nv = ctx->nv; mv.nvp = (ctx->nv + 3) & ~3;
     mv.llc0 = ctx->llc[0]; mv.llc1 = ctx->llc[1]; mv.res0 = ctx->res[0]; mv.res1 = ctx->res[1];
     mv.urc0 = ctx->urc[0]; mv.urc1 = ctx->urc[1];

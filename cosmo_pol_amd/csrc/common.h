@@ -70,6 +70,7 @@ struct ClassTable {
 
 struct ModelView {
     const float *zcol;             // [ny][nx][nz]     heights, level index fastest
+    const float *zc8;              // [ny][nx][8]      heights at levels (k (nz - 1)) / 7, k = 0..7
     const float *dcol;             // [ny][nx][nz][nvp] variables interleaved per level, nvp = nv rounded up to 4
     int   nz, ny, nx, nv, nvp;
     float llc0, llc1, res0, res1;  // (Lo1, La1), (dlon, dlat)
@@ -105,7 +106,7 @@ struct cpol_ctx {
     bool have_cfg = false, have_model = false;
     cpol_config cfg;
     // model
-    float *zcol = nullptr, *dcol = nullptr;
+    float *zcol = nullptr, *dcol = nullptr, *zc8 = nullptr;
     int nz = 0, ny = 0, nx = 0, nv = 0;
     int var_ids[CPOL_MAX_VARS];
     float llc[2], urc[2], res[2];
@@ -154,6 +155,7 @@ struct cpol_ctx {
 
 // kernels.hip
 void launch_transpose_levels(hipStream_t s, const float *src, float *dst, int nz, long ncell, int stride, int offset);
+void launch_coarse_levels(hipStream_t s, const float *zcol, float *zc8, int nz, long ncell);
 void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *az, const double *el,
                  const double *quad, double *line, float *S, float *H, float *E, double *lat, double *lon,
                  float *coords, double *phi, const ModelView &mv, int *status);

@@ -321,6 +321,22 @@ void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *
                        S, H, E, lat, lon, coords, mv, status);
 }
 
+// Eight heights of every column, at levels (k (nz - 1)) / 7, k = 0..7: the model top, the terrain and six levels
+// in between, 32 bytes that start the level search of k_interp with one access instead of three bisection steps.
+__global__ void k_coarse_levels(const float *__restrict__ zcol, float *__restrict__ zc8, int nz, long ncell)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncell * 8) return;
+    const long c = t >> 3;
+    const int k = (int)(t & 7);
+    zc8[t] = zcol[c * nz + (k * (nz - 1)) / 7];
+}
+
+void launch_coarse_levels(hipStream_t s, const float *zcol, float *zc8, int nz, long ncell)
+{
+    hipLaunchKernelGGL(k_coarse_levels, dim3((unsigned)((ncell * 8 + 255) / 256)), dim3(256), 0, s, zcol, zc8, nz, ncell);
+}
+
 // =============================================================================
 // trilinear interpolation (interpolation_c.c:12-164), one thread per point, every
 // variable in one pass.  The level search is the reference's loop, so the chosen
@@ -384,16 +400,22 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     } else {
         cell[0] = (long)iy * mv.nx + ix; cell[1] = cell[0] + 1;
         cell[2] = cell[0] + mv.nx;       cell[3] = cell[2] + 1;
-        float t0 = mv.zcol[cell[0] * nz + nz - 1], t1 = mv.zcol[cell[1] * nz + nz - 1];
-        float t2 = mv.zcol[cell[2] * nz + nz - 1], t3 = mv.zcol[cell[3] * nz + nz - 1];
+        // top, terrain and six levels in between of the four columns
+        const float4 *q = (const float4 *)(mv.zc8 + cell[0] * 8);
+        const float4 q0 = q[0], q1 = q[1];
+        const float ck[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        float ztop[4], zbot[4];
+        ztop[0] = ck[0]; zbot[0] = ck[7];
+#pragma unroll
+        for (int j = 1; j < 4; j++) { ztop[j] = mv.zc8[cell[j] * 8]; zbot[j] = mv.zc8[cell[j] * 8 + 7]; }
+        const float t0 = zbot[0], t1 = zbot[1], t2 = zbot[2], t3 = zbot[3];
         float topo = dx * dy * t0 + x * t2 * dy + dx * t1 * y + x * y * t3;
         if (!(topo < H)) code = 1;
         else {
             // The level search of interpolation_c.c:108-135 on a strictly descending column returns the last
             // level that is not below H (an exact hit on a level returns that level, a hit on the lowest one
             // the level above it), i.e. (number of levels >= H) - 1 capped at nz - 2; "above the top" and "below
-            // the lowest level" are decided first, as there.  The count comes from a fixed-length, branch-free
-            // bisection, the four columns in lockstep.
+            // the lowest level" are decided first, as there.
             const float *col[4];
             int res[4];
             bool above = false;
@@ -401,22 +423,42 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 col[j] = mv.zcol + cell[j] * nz;
-                float top = col[j][0];
-                float bot = (j == 0) ? t0 : (j == 1) ? t1 : (j == 2) ? t2 : t3;   // col[j][nz-1]
-                above = above || (H > top);
-                below[j] = H < bot;
+                above = above || (H > ztop[j]);
+                below[j] = H < zbot[j];
                 res[j] = 0;
             }
             if (above) code = -1;
             else {
                 int cnt[4] = {0, 0, 0, 0};
-                // column 0 by bisection; the levels of the three neighbours lie close to it (terrain-following
-                // coordinates), so their counts are read off a window of four heights around column 0's
-                // count, and only a column whose window does not bracket H is bisected as well
-                for (int step = 1 << (31 - __clz(nz)); step > 0; step >>= 1) {
-                    const bool in = cnt[0] + step <= nz;
-                    const float v = col[0][in ? cnt[0] + step - 1 : 0];
-                    if (in && v >= H) cnt[0] += step;
+                // Column 0: the eight coarse heights bracket the count between two of their levels, and the levels
+                // in between are searched four ways at a time (three independent probes per round: two rounds for
+                // up to 15 levels) - three dependent memory accesses where a bisection takes log2(nz).
+                // The levels of the three neighbours lie close to it (terrain-following coordinates), so their
+                // counts are read off a window of four heights around column 0's count, and only a column whose
+                // window does not bracket H is searched on its own.
+                {
+                    int kk = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) kk += ck[k] >= H ? 1 : 0;          // >= 1: H is not above the top
+                    const int c_hi = kk < 8 ? (kk * (nz - 1)) / 7 : nz;             // first coarse level below H
+                    int lo = ((kk - 1) * (nz - 1)) / 7 + 1;                         // levels before lo are >= H
+                    int nn = kk < 8 ? c_hi - lo : 0;                                // undecided levels lo .. lo + nn - 1
+                    while (__any(nn > 0)) {
+                        const int m = (nn + 3) >> 2;
+                        int c = 0;
+#pragma unroll
+                        for (int i = 1; i <= 3; i++) {
+                            const int off = i * m - 1;
+                            const bool in = nn > 0 && off < nn;
+                            const float v = col[0][in ? lo + off : 0];
+                            c += (in && v >= H) ? 1 : 0;
+                        }
+                        if (nn > 0) {
+                            lo += c * m;
+                            nn = c == 3 ? nn - 3 * m : min(m - 1, nn - c * m);     // no fourth probe bounds the last run
+                        }
+                    }
+                    cnt[0] = kk < 8 ? lo : nz;
                 }
                 bool redo[4] = {false, false, false, false};
                 {
