@@ -361,6 +361,7 @@ __device__ inline int level_search(const float *__restrict__ col, int dim, float
 
 #define INTERP_XCD_RUN 72
 #define INTERP_REC 17
+#define INTERP_BATCH 4
 __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords, const float *__restrict__ Hh,
                          float *__restrict__ vals, long plane, signed char *__restrict__ mask,
                          float *__restrict__ raw_out)
@@ -540,11 +541,11 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
         const int nq = mv.nvp >> 2;
         const bool kact = k < nq;
         const float4 *dlane = (const float4 *)mv.dcol + (kact ? k : 0);
-        for (int p4 = 0; p4 < 16; p4 += 4) {
-            // issue the loads of four groups of four points before using any of them
-            float4 va[4], vb[4];
+        for (int p4 = 0; p4 < 16; p4 += INTERP_BATCH) {
+            // issue the loads of INTERP_BATCH groups of four points before using any of them
+            float4 va[INTERP_BATCH], vb[INTERP_BATCH];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < INTERP_BATCH; i++) {
                 const float *pr = s_rec[wv][4 * (p4 + i) + grp];
                 // a point outside the model reads the first column instead: its results are never used
                 const int b = __float_as_int(pr[14]) == 0 ? __float_as_int(pr[j]) : 0;
@@ -552,7 +553,7 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
                 vb[i] = dlane[b + nq];
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < INTERP_BATCH; i++) {
                 // nothing to do for four points that all lie outside the model (the tail of a ray above the model
                 // top, the gates below the terrain): their outputs are sentinels
                 float *pr = s_rec[wv][4 * (p4 + i) + grp];
