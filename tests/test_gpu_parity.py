@@ -244,6 +244,42 @@ def test_interp_points_bit_exact():
         np.testing.assert_array_equal(out[i][ok].view(np.int32), want[ok].view(np.int32))
 
 
+@pytest.mark.parametrize('nz', [3, 4, 7, 8, 9, 15, 33, 64, 80, 113])
+def test_interp_level_search_any_level_count(nz):
+    """The level search starts from eight coarse heights at levels k (nz - 1) / 7 and narrows four ways at a
+    time: every level count from the smallest the library accepts, points on exact level heights, points above
+    the top, below the lowest level and below the terrain, bit for bit against the C restatement
+    (interpolation_c.c:108-135)."""
+    m = syn.synthetic_model(nz=nz, ny=24, nx=28, scheme=1, seed=1000 + nz, llc=(-1.0, -0.8), res=(0.05, 0.04), ztop=9000.)
+    conf = O.make_config(microphysics={'scheme': 1})
+    eng = engine.Engine(conf, device=0)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    rng = np.random.default_rng(nz)
+    n = 6000
+    coords = np.empty((n, 2), dtype='float32')
+    coords[:, 0] = -0.8 + 0.04 * rng.uniform(0, 22.99, n)
+    coords[:, 1] = -1.0 + 0.05 * rng.uniform(0, 26.99, n)
+    H = rng.uniform(-200., 9800., n).astype('float32')
+    # a third of the points sit exactly on a level height of their lower-left column
+    zlev = np.asarray(m['zlev'], dtype='float32')
+    llc = np.array([-1.0, -0.8], dtype='float32')
+    res = np.array([0.05, 0.04], dtype='float32')
+    iy = np.floor((coords[:, 0] - llc[1]) / res[1]).astype(int)
+    ix = np.floor((coords[:, 1] - llc[0]) / res[0]).astype(int)
+    lev = rng.integers(0, nz, n)
+    hit = rng.uniform(size=n) < 1. / 3
+    H[hit] = zlev[lev[hit], iy[hit], ix[hit]]
+    out = eng.ctx.interp_points(coords, H)
+    seen = 0
+    for i, name in enumerate(m['fields'].keys()):
+        want = O.interp_c(coords, H, m['fields'][name], zlev, llc, res)
+        np.testing.assert_array_equal(np.isnan(out[i]), np.isnan(want), err_msg=name)
+        ok = ~np.isnan(want)
+        np.testing.assert_array_equal(out[i][ok].view(np.int32), want[ok].view(np.int32), err_msg=name)
+        seen = max(seen, int((ok & (want != -9999.)).sum()))
+    assert seen > n // 4
+
+
 def test_get_all_radar_pts_dropin():
     """The reference's C symbol, same signature, served by the GPU."""
     import ctypes as C
