@@ -17,8 +17,8 @@ OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_DOMAIN, ERR_REFRACTION = 0, 1, 2, 3, 4, 5
 N_OBS = 9
 OBS_NAMES = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'AH', 'AV']
 VAR_SLOTS = {'U': 0, 'V': 1, 'W': 2, 'QR_v': 3, 'QS_v': 4, 'QG_v': 5, 'RHO': 6, 'T': 7,
-             'QH_v': 8, 'QNH_v': 9, 'QNR_v': 10, 'QNS_v': 11, 'QNG_v': 12}
-V_COUNT = 13
+             'QH_v': 8, 'QNH_v': 9, 'QNR_v': 10, 'QNS_v': 11, 'QNG_v': 12, 'EDR': 13}
+V_COUNT = 14
 CLASS_INDEX = {'R': 0, 'S': 1, 'G': 2, 'H': 3}
 
 c_float_p = C.POINTER(C.c_float)
@@ -55,7 +55,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -89,6 +89,7 @@ def load():
     lib.cpol_upload_lut.argtypes = [vp, C.c_int, C.POINTER(CpolLut), C.POINTER(CpolPsd), C.POINTER(CpolPsd)]
     lib.cpol_set_quadrature.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p]
     lib.cpol_set_velocity_bins.argtypes = [vp, C.c_int, c_double_p]
+    lib.cpol_set_turbulence.argtypes = [vp, C.c_int, C.c_double, C.c_double]
     lib.cpol_set_refraction_table.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_float_p, c_float_p]
     lib.cpol_run_rays.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_run_rays_dev.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
@@ -241,6 +242,10 @@ class Context(object):
         v = np.ascontiguousarray(varray, dtype=np.float64)
         self._check(self.lib.cpol_set_velocity_bins(self.h, len(v), dptr(v)), 'cpol_set_velocity_bins')
         self.n_vel = len(v)
+
+    def set_turbulence(self, enable, beamwidth_deg=1.0, kolmogorov_a=1.6):
+        self._check(self.lib.cpol_set_turbulence(self.h, int(bool(enable)), float(beamwidth_deg), float(kolmogorov_a)),
+                    'cpol_set_turbulence')
 
     def set_refraction_table(self, keys=None, S=None, H=None, E=None):
         """keys: ascending total elevations; S, H, E: [len(keys), n_gates].  No arguments: back to the 4/3 model."""

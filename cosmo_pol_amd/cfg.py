@@ -29,7 +29,7 @@ VALID_VALUES = {
     'integration': {'scheme': [1, 2, 3, 4], 'nv_GH': np.arange(1, 31, 2), 'nh_GH': np.arange(1, 31, 2),
                     'n_gaussians': np.arange(1, 13, 2), 'weight_threshold': [0., 'to', 1.],
                     'nr_GH': np.arange(1, 31, 2), 'na_GL': np.arange(1, 31, 2)},
-    'doppler': {'scheme': [1, 2, 3], 'turbulence_correction': [0, 1]},
+    'doppler': {'scheme': [1, 2, 3, 4], 'turbulence_correction': [0, 1]},      # 4: doppler_sz.py:36 (3 + turbulence)
     'microphysics': {'scheme': [1, 2]},
 }
 

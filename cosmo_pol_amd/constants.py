@@ -15,6 +15,7 @@ C = 299792458.
 RHO_W = 1000. / (1000 ** 3)
 RHO_I = 916. / (1000 ** 3)
 KW = 0.93
+A = 1.6                    # Kolmogorov constant of the turbulence spread (constants.py:40)
 RHO_0 = 1.225
 MAX_HEIGHT_COSMO = 35000
 SIMULATED_VARIABLES = ['ZH', 'DSPECTRUM', 'RVEL', 'ZV', 'PHIDP', 'ZDR', 'RHOHV', 'KDP']
@@ -26,6 +27,7 @@ class Constant_class(object):
 
     def __init__(self):
         self.EPS, self.C, self.KW, self.RHO_W, self.RHO_I, self.RHO_0 = EPS, C, KW, RHO_W, RHO_I, RHO_0
+        self.A = A
         self.SIMULATED_VARIABLES = SIMULATED_VARIABLES
         self.MAX_HEIGHT_COSMO = MAX_HEIGHT_COSMO
         self.update()

@@ -292,6 +292,17 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
     return CPOL_OK;
 }
 
+extern "C" int cpol_set_turbulence(cpol_ctx *ctx, int enable, double beamwidth_deg, double kolmogorov_a)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    if (enable && (!(beamwidth_deg > 0) || !(kolmogorov_a > 0)))
+        return fail(ctx, CPOL_ERR_ARG, "turbulence broadening needs a positive beamwidth and Kolmogorov constant");
+    ctx->turb = enable ? 1 : 0;
+    ctx->turb_beamwidth = beamwidth_deg;
+    ctx->turb_a = kolmogorov_a;
+    return CPOL_OK;
+}
+
 extern "C" int cpol_set_velocity_bins(cpol_ctx *ctx, int n_vel, const double *varray)
 {
     if (!ctx || n_vel < 2 || n_vel > 4096 || !varray) return CPOL_ERR_ARG;
@@ -552,6 +563,18 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         SpecParams sp;
         memset(&sp, 0, sizeof(sp));
         sp.n_gates = G; sp.n_sub = B; sp.n_vel = ctx->n_vel; sp.zfac = op.zfac;
+        if (ctx->turb) {
+            bool have_edr = false;
+            for (int i = 0; i < ctx->nv; i++) have_edr = have_edr || ctx->var_ids[i] == CPOL_V_EDR;
+            if (!have_edr && ctx->have_model)
+                return fail(ctx, CPOL_ERR_STATE, "turbulence broadening: the model state has no eddy dissipation rate (CPOL_V_EDR)");
+            if (ctx->n_vel > 2048) return fail(ctx, CPOL_ERR_ARG, "turbulence broadening handles at most 2048 velocity bins");
+            sp.turb = 1;
+            sp.sigma_r = ctx->cfg.range_res;
+            sp.sigma_theta = ctx->turb_beamwidth * (M_PI / 180.0);
+            sp.kolm_a = ctx->turb_a;
+            sp.range_res = ctx->cfg.range_res;
+        }
         for (int h = 0; h < 3; h++) {
             const cpol_psd &pd = ctx->lut[h].psd_dop;
             sp.d_min[h] = (float)pd.d_min; sp.d_max[h] = (float)pd.d_max; sp.step[h] = ctx->lut[h].dD;

@@ -117,6 +117,8 @@ struct cpol_ctx {
     std::vector<double> az_off, el_off, weight;
     double *quad_dev = nullptr;    // [3][n_sub]: az_off, el_off, weight
     int n_vel = 0;                 // Doppler spectrum bins (constants.py:75 VARRAY)
+    int turb = 0;                  // turbulence broadening of the spectrum
+    double turb_beamwidth = 0., turb_a = 1.6;
     double *varray_dev = nullptr;
     const float **rawptr_dev = nullptr;   // [2][CPOL_MAX_CLASSES]: raw tables, diameter axes
     int n_refr = 0;                       // refraction table (cpol_set_refraction_table)
@@ -187,6 +189,11 @@ struct SpecParams {
     float  d_min[3], d_max[3], step[3];
     double inv_alpha[3], inv_beta[3];   // get_D_from_V: (1/alpha * v)^(1/beta)
     float  mu[3], nu[3];
+    // turbulence broadening (off when turb == 0)
+    int    turb;
+    double sigma_r, sigma_theta;   // radial resolution [m], 3 dB beamwidth [rad]
+    double kolm_a;                 // constants.A
+    double range_res;              // gate g lies at range_res * (g + 0.5) (constants.py RANGE_RADAR)
 };
 
 void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, int n_rays, long nu, const float *vals,

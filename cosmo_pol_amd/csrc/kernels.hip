@@ -1748,6 +1748,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
     extern __shared__ double sm[];
     double *term = sm;                       // [3][1024]
     double *acc = sm + 3 * 1024;             // [n_vel]
+    double *bs = acc + sp.n_vel;             // [n_vel] one sub-beam's weighted spectrum (turbulence broadening only)
     const int lane = threadIdx.x;
     const int G = sp.n_gates, B = sp.n_sub, NV = sp.n_vel;
     const int r = blockIdx.x / G, g = blockIdx.x % G;
@@ -1801,6 +1802,10 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
         const double hor = (Uw * phi_sc[2 * rb] + Vw * phi_sc[2 * rb + 1]) / (double)(float)tan((double)th);
         const double sth = (double)(float)sin((double)th);
         const double w = wsub[b];
+        if (sp.turb) {
+            for (int i = lane; i < NV; i += 64) bs[i] = 0.;
+            __syncthreads();
+        }
         for (int i = lane; i < NV - 1; i += 64) {
             double wh0 = (double)rinv * (Ww + hor - varray[i] / sth);
             double wh1 = (double)rinv * (Ww + hor - varray[i + 1] / sth);
@@ -1832,9 +1837,61 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                 }
             }
             refl *= sp.zfac;
-            acc[i] += (double)refl * w;
+            if (sp.turb) bs[i] = (double)refl * w;
+            else acc[i] += (double)refl * w;
         }
         __syncthreads();
+        if (sp.turb) {
+            // Spectrum spread by turbulence (doppler_sz.py:94-96).  Standard deviation after Doviak and Zrnic
+            // (get_turb_std, :308-321, with true division), in velocity bins; then gaussian_filter1d of the bins
+            // (reflecting edges, radius int(4 sigma + 0.5), normalised weights) and rescaling to the power the
+            // sub-beam's spectrum had before (turb_spectrum_spread, :323-335).
+            const double edr = (double)vals[(long)CPOL_V_EDR * plane + u];
+            const double rng = sp.range_res * ((double)g + 0.5);
+            const double rt = rng * sp.sigma_theta;
+            double tstd;
+            if (sp.sigma_r < 0.1 * rt) tstd = cbrt((rng * edr * sp.sigma_theta * sp.kolm_a * sqrt(sp.kolm_a)) / 0.72);
+            else {
+                const double a135 = 1.35 * sp.kolm_a, ratio = rt / sp.sigma_r;
+                const double den = 11. / 15. + 4. / 15. * ratio * ratio;
+                tstd = cbrt((edr * sp.sigma_r * a135 * sqrt(a135)) * (den * sqrt(den)));      // x / den^(-3/2)
+            }
+            const double sig = tstd / (varray[2] - varray[1]);
+            if (!(sig > 1e-15)) {                 // no spread (scipy skips such an axis); NaN falls here as well
+                for (int i = lane; i < NV; i += 64) acc[i] += bs[i];
+            } else {
+                int R = (int)fmin(4.0 * sig + 0.5, 1023.0);                // weights live in term[0 .. R]
+                const double c = -0.5 / (sig * sig);
+                double ws = 0., p0 = 0.;
+                for (int k = lane; k <= R; k += 64) {
+                    const double wk = exp(c * (double)k * (double)k);
+                    term[k] = wk;
+                    ws += k == 0 ? wk : 2. * wk;
+                }
+                for (int i = lane; i < NV; i += 64) p0 += bs[i];
+                for (int off = 32; off > 0; off >>= 1) { ws += __shfl_xor(ws, off); p0 += __shfl_xor(p0, off); }
+                __syncthreads();
+                double *cv = term + 1024;                                   // [n_vel <= 2048] convolved bins
+                double p1 = 0.;
+                for (int i = lane; i < NV; i += 64) {
+                    double a = 0.;
+                    for (int k = -R; k <= R; k++) {
+                        int idx = i + k;
+                        // half-sample symmetric extension: d c b a | a b c d | d c b a
+                        while (idx < 0 || idx >= NV) idx = idx < 0 ? -1 - idx : 2 * NV - 1 - idx;
+                        a += term[k < 0 ? -k : k] * bs[idx];
+                    }
+                    a /= ws;
+                    cv[i] = a;
+                    p1 += a;
+                }
+                for (int off = 32; off > 0; off >>= 1) p1 += __shfl_xor(p1, off);
+                // an all-zero spectrum stays all zero (the reference's 0 / 0 would turn the gate into NaN)
+                if (p1 != 0.)
+                    for (int i = lane; i < NV; i += 64) acc[i] += cv[i] / p1 * p0;
+            }
+            __syncthreads();
+        }
     }
     // spectrum and its first moment (doppler_sz.py:99)
     double s0 = 0., s1 = 0.;
@@ -1853,7 +1910,7 @@ void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, 
                      const double *varray, const float *const *raw, const float *const *d_axis, double *spectrum,
                      double *rvel, long ray0)
 {
-    size_t lds = (size_t)(3 * 1024 + sp.n_vel) * sizeof(double);
+    size_t lds = (size_t)(3 * 1024 + sp.n_vel * (sp.turb ? 2 : 1)) * sizeof(double);
     hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((long)n_rays * sp.n_gates)), dim3(64), lds, s, ct, sp, nu, vals, plane,
                        elev, mask, wsub, phi_sc, varray, raw, d_axis, spectrum, rvel, ray0);
 }

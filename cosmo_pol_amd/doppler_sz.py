@@ -11,8 +11,8 @@ from .scattering_sz import _pack
 
 def get_doppler_velocity(list_beams, lut_sz=0, device=0):
     scheme = cfg.CONFIG['doppler']['scheme']
-    if scheme not in (1, 2, 3):
-        raise ValueError("doppler.scheme must be 1, 2 or 3, got %r" % (scheme,))
+    if scheme not in (1, 2, 3, 4):
+        raise ValueError("doppler.scheme must be 1, 2, 3 or 4, got %r" % (scheme,))
     st = runtime.get_engine(device, doppler=scheme)
     if lut_sz:
         runtime.ensure_luts(st, lut_sz)
@@ -30,6 +30,6 @@ def get_doppler_velocity(list_beams, lut_sz=0, device=0):
         mask_out[np.logical_and(mask_out >= 0, mask_out < 1)] = 0
     c = list_beams[int(len(list_beams) / 2)]
     vals_out = {'RVEL': rvel}
-    if scheme == 3:
+    if scheme in (3, 4):
         vals_out['DSPECTRUM'] = st.eng.ctx.last_spectrum                 # doppler_sz.py:123
     return Beam(vals_out, mask_out, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)

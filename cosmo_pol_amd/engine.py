@@ -38,6 +38,11 @@ class Engine(object):
         rr = radar_ranges(conf)
         wl = cst.C / (r['frequency'] * 1E09) * 1000
         dscheme = conf['doppler']['scheme'] if doppler is None else doppler
+        # Scheme 4 is the reference's name for the spectrum with turbulence broadening (doppler_sz.py:36); the
+        # option file's doppler.turbulence_correction asks for the same on top of scheme 3.
+        self.turbulence = int(dscheme) == 4 or (int(dscheme) == 3 and bool(conf['doppler'].get('turbulence_correction', 0)))
+        if int(dscheme) == 4:
+            dscheme = 3
         sens = r['sensitivity']
         if not isinstance(sens, (list, tuple)):
             sens = [sens]
@@ -57,8 +62,21 @@ class Engine(object):
             vres = 2 * nvel / r['FFT_length']
             self.varray = np.arange(-nvel, nvel + vres, vres)                    # constants.py:73-75
             self.ctx.set_velocity_bins(self.varray)
+        self.beamwidth = float(r.get('3dB_beamwidth', 1.0))
+        self._apply_turbulence()
         self.conf = conf
         self.n_gates = len(rr)
+
+    def _apply_turbulence(self):
+        """Turbulence broadening needs the eddy dissipation rate among the model variables; without it the
+        reference falls back to the plain spectrum with a message (doppler_sz.py:36-41)."""
+        on = getattr(self, 'turbulence', False)
+        names = getattr(self, 'model_names', None)
+        if on and names is not None and 'EDR' not in names:
+            print('No eddy dissipitation rate variable found in COSMO file, could not use doppler_scheme == 4, '
+                  'using doppler_scheme == 3 instead')
+            on = False
+        self.ctx.set_turbulence(on, getattr(self, 'beamwidth', 1.0), cst.A)
 
     def set_gauss_hermite(self):
         az, el, w = gauss_hermite_subbeams(self.conf)
@@ -103,3 +121,5 @@ class Engine(object):
         urc = (float(proj_info['Lo2']), float(proj_info['La2']))
         pole = (float(proj_info['Latitude_of_southern_pole']), float(proj_info['Longitude_of_southern_pole']))
         self.ctx.upload_model(fields, zlev, llc, urc, resolution, pole)
+        self.model_names = list(fields.keys())
+        self._apply_turbulence()

@@ -64,6 +64,8 @@ class RadarOperator(object):
             raise ValueError('Not all necessary variables could be found in file: missing %s' % missing)
         two_mom = all(v in dic for v in BASE_VARIABLES_2MOM)
         names = BASE_VARIABLES + (BASE_VARIABLES_2MOM if two_mom else [])
+        if 'EDR' in dic:                 # eddy dissipation rate: turbulence broadening of the spectrum (doppler_sz.py:36)
+            names = names + ['EDR']
         self.dic_vars = {k: dic[k] for k in names}
         self.N = dic['N'] if 'N' in dic else 0          # refractivity, kept apart (radar_operator.py:141-143)
         cfg.CONFIG['microphysics']['scheme'] = 2 if two_mom else 1
@@ -80,8 +82,8 @@ class RadarOperator(object):
         if self.lut_sz is None:
             raise RuntimeError('lookup tables not set: call set_lut(scheme, lut) first')
         dscheme = cfg.CONFIG['doppler']['scheme']
-        if dscheme not in (1, 2, 3):
-            raise ValueError('doppler.scheme must be 1, 2 or 3, got %r' % (dscheme,))
+        if dscheme not in (1, 2, 3, 4):
+            raise ValueError('doppler.scheme must be 1, 2, 3 or 4, got %r' % (dscheme,))
         st = runtime.get_engine(self.device, doppler=dscheme, sensitivity_cut=True)
         runtime.ensure_luts(st, self.lut_sz)
         runtime.ensure_model(st, self.dic_vars)
@@ -103,7 +105,7 @@ class RadarOperator(object):
         out = ctx.run_rays(azs[idx], els[idx])      # raises IndexError when a gate leaves the model domain
         fields = {n: out['obs'][i] for i, n in enumerate(OBS_NAMES)}
         fields['RVEL'] = out['rvel']
-        if dscheme == 3:
+        if dscheme in (3, 4):
             fields['DSPECTRUM'] = out['dspectrum']              # [n_rays, n_gates, n_velocity_bins]
         extra = {'mask': out['mask'], 'lat': out['lat'], 'lon': out['lon'], 'height': out['height']}
         if world > 1:

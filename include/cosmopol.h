@@ -35,7 +35,9 @@ typedef struct cpol_ctx cpol_ctx;
 /* Variable slots of the model state (radar_operator.py:32-33, BASE_VARIABLES[_2MOM]). */
 enum cpol_var {
     CPOL_V_U = 0, CPOL_V_V, CPOL_V_W, CPOL_V_QR, CPOL_V_QS, CPOL_V_QG, CPOL_V_RHO, CPOL_V_T,
-    CPOL_V_QH, CPOL_V_QNH, CPOL_V_QNR, CPOL_V_QNS, CPOL_V_QNG, CPOL_V_COUNT
+    CPOL_V_QH, CPOL_V_QNH, CPOL_V_QNR, CPOL_V_QNS, CPOL_V_QNG,
+    CPOL_V_EDR,           /* eddy dissipation rate, read by the turbulence broadening only (doppler_sz.py:36,95) */
+    CPOL_V_COUNT
 };
 
 /* Order of the observables in every output array. */
@@ -143,6 +145,17 @@ int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd 
 /* Velocity bins of the Doppler spectrum: constants.VARRAY = arange(-NVEL, NVEL + VRES, VRES)
  * (constants/constants.py:73-75).  Needed for doppler_scheme 3. */
 int cpol_set_velocity_bins(cpol_ctx *ctx, int n_vel, const double *varray);
+
+/* Turbulence broadening of the Doppler spectrum (doppler_sz.py:94-96, get_turb_std :308-321,
+ * turb_spectrum_spread :323-335).  With enable != 0 and doppler_scheme 3 every sub-beam's weighted spectrum is
+ * convolved along the velocity axis with a Gaussian whose standard deviation follows Doviak and Zrnic from the
+ * eddy dissipation rate (model variable CPOL_V_EDR, which must have been uploaded), the gate's range, the
+ * radial resolution and the 3 dB beamwidth, and rescaled to its power before the convolution.  The reference
+ * cannot reach this code (it asks for scheme 4 inside the scheme-3 branch) and its formula relies on Python-2
+ * integer division; this entry point implements the formula with true division, one standard deviation per gate,
+ * the filter being scipy.ndimage.gaussian_filter1d's (reflecting edges, truncated at four standard deviations).
+ * beamwidth_deg = radar.3dB_beamwidth, kolmogorov_a = constants.A (1.6). */
+int cpol_set_turbulence(cpol_ctx *ctx, int enable, double beamwidth_deg, double kolmogorov_a);
 
 /* Antenna quadrature: the kept sub-beams of interpolation/interpolation.py:260-279 in
  * reference order, as offsets (degrees) added to the ray's azimuth / elevation and

@@ -610,9 +610,52 @@ def get_doppler_spectrum(beam, hydros, luts, cfg, consts, get_refl=get_refl_np):
     return refl
 
 
+def get_turb_std(ranges, EDR, cfg):
+    """doppler/doppler_sz.py:308-321 with true division (the reference's (3/2) and (1/3) are Python-2 integer
+    divisions, which would make every standard deviation 1): Doviak and Zrnic's two regimes of the turbulence
+    spread.  PARITY UNPINNED: the reference cannot reach this function (it tests for scheme 4 inside the
+    scheme-3 branch, doppler_sz.py:36,89), so there is no output of it to compare with."""
+    sigma_r = cfg['radar']['radial_resolution']
+    sigma_theta = cfg['radar']['3dB_beamwidth'] * DEG2RAD
+    A = 1.6                                                        # constants.py:40
+    ranges = np.asarray(ranges, dtype=np.float64)
+    EDR = np.asarray(EDR, dtype=np.float64)
+    std = np.zeros((len(EDR),))
+    with np.errstate(invalid='ignore'):
+        c1 = sigma_r < 0.1 * ranges * sigma_theta
+        std[c1] = np.cbrt((ranges[c1] * EDR[c1] * sigma_theta * A ** 1.5) / 0.72)
+        c2 = ~c1
+        std[c2] = np.cbrt((EDR[c2] * sigma_r * (1.35 * A) ** 1.5)
+                          / (11. / 15. + 4. / 15. * (ranges[c2] * sigma_theta / sigma_r) ** 2) ** (-1.5))
+    return std
+
+
+def turb_spectrum_spread(spectrum, turb_std, varray):
+    """doppler/doppler_sz.py:323-335, one standard deviation per gate (the reference hands the whole vector to
+    gaussian_filter as if it were one sigma per axis): every gate's spectrum is filtered along the velocity
+    axis (scipy's defaults: reflecting edges, truncation at 4 sigma) and rescaled to its power before.  Rows with
+    a standard deviation that is zero, negative or NaN, and all-zero rows, are left as they are."""
+    from scipy.ndimage import gaussian_filter1d
+    v_res = varray[2] - varray[1]
+    out = np.array(spectrum, dtype=np.float64)
+    for i in range(out.shape[0]):
+        sig = turb_std[i] / v_res
+        if not sig > 1e-15:
+            continue
+        p0 = np.sum(out[i])
+        f = gaussian_filter1d(out[i], sig)
+        p1 = np.sum(f)
+        if p1 != 0:
+            out[i] = f / p1 * p0
+    return out
+
+
 def get_doppler_velocity(list_beams, luts, cfg, get_refl=get_refl_np):
-    """doppler/doppler_sz.py:26-128 (schemes 1, 2, 3)."""
+    """doppler/doppler_sz.py:26-128 (schemes 1, 2, 3; scheme 4 or doppler.turbulence_correction = scheme 3 with
+    the turbulence spread of every sub-beam's weighted spectrum, :94-96, when the beams carry 'EDR')."""
     dscheme = cfg['doppler']['scheme']
+    add_turb = (dscheme == 4 or (dscheme == 3 and cfg['doppler'].get('turbulence_correction', 0))) \
+        and 'EDR' in list_beams[0].values
     consts = radar_constants(cfg)
     num_beams = len(list_beams)
     len_beams = max([len(l.dist_profile) for l in list_beams])
@@ -636,7 +679,12 @@ def get_doppler_velocity(list_beams, luts, cfg, get_refl=get_refl_np):
     else:
         spectrum = np.zeros((len_beams, len(consts['VARRAY'])))
         for beam in list_beams:
-            spectrum += get_doppler_spectrum(beam, hydros, luts, cfg, consts, get_refl) * beam.GH_weight
+            bs = get_doppler_spectrum(beam, hydros, luts, cfg, consts, get_refl) * beam.GH_weight
+            if add_turb:
+                rr = cfg['radar']['radial_resolution']
+                ranges = np.arange(rr / 2., cfg['radar']['range'], rr)[:bs.shape[0]]       # constants.py RANGE_RADAR
+                bs = turb_spectrum_spread(bs, get_turb_std(ranges, beam.values['EDR'], cfg), consts['VARRAY'])
+            spectrum += bs
         with np.errstate(invalid='ignore', divide='ignore'):
             rvel = np.sum(np.tile(consts['VARRAY'], (len_beams, 1)) * spectrum, axis=1) / np.sum(spectrum, axis=1)
     mask = np.zeros(len_beams,)

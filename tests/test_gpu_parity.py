@@ -188,6 +188,77 @@ def test_doppler_spectrum_vs_oracle(n_gates, n_sub):
     util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=0.02 if n_moved else 1e-6, name='RVEL')
 
 
+def _beams_with_edr(n_gates, n_sub, seed):
+    beams = syn.synthetic_beams(n_gates, n_sub, 1, seed=seed, res=250., elevation=12.0, nan_tail=4, below_head=2)
+    rng = np.random.default_rng(seed)
+    for b in beams:
+        edr = (10. ** rng.uniform(-5., -1., n_gates)).astype('float32')           # m^2 s^-3
+        edr[rng.uniform(size=n_gates) < 0.1] = 0.                                 # no turbulence: no spread
+        edr[np.isnan(b['values']['T'])] = np.nan
+        b['values']['EDR'] = edr
+    return beams
+
+
+def test_turbulence_spread_of_one_subbeam():
+    """With one sub-beam the spectrum without broadening is the sub-beam's own, so broadening it on the host
+    (the oracle's gaussian_filter1d per gate + power rescaling) must reproduce the kernel's broadened spectrum
+    to rounding: this isolates the convolution from the float32 sin / tan sensitivity of the bin edges.
+    Parity of the broadening itself is unpinned: the reference cannot reach it (doppler_sz.py:36,89)."""
+    n_gates = 48
+    base = dict(microphysics={'scheme': 1}, radar={'frequency': 5.6, 'radial_resolution': 250., 'PRI': 1000,
+                                                   'FFT_length': 128, '3dB_beamwidth': 1.45})
+    beams = _beams_with_edr(n_gates, 9, seed=404)[5:6]          # one off-axis sub-beam with its weight
+    conf3 = O.make_config(doppler={'scheme': 3}, **base)
+    eng = make_engine(conf3)
+    eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    plain = eng.ctx.last_spectrum.copy()
+    conf4 = O.make_config(doppler={'scheme': 4}, **base)
+    eng.configure(conf4)
+    _, _, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    got = eng.ctx.last_spectrum
+    consts = O.radar_constants(conf4)
+    ranges = np.arange(125., 125. + 250. * n_gates, 250.)
+    std = O.get_turb_std(ranges, beams[0]['values']['EDR'], conf4)
+    assert np.nanmax(std) / (consts['VARRAY'][2] - consts['VARRAY'][1]) > 3.          # several bins wide somewhere
+    want = O.turb_spectrum_spread(plain, std, consts['VARRAY'])
+    assert (plain != 0).sum() > 100 and (want != plain).any()
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    err = np.abs(got - want) / np.maximum(peak, 1e-300)
+    assert err.max() < 1e-12, "gate %d: %.3e of the peak" % (int(err.max(axis=1).argmax()), err.max())
+    np.testing.assert_allclose(got.sum(axis=1), plain.sum(axis=1), rtol=1e-12)          # power is kept
+    with np.errstate(all='ignore'):
+        rv = (consts['VARRAY'][None, :] * want).sum(axis=1) / want.sum(axis=1)
+    util.assert_close(rvel, rv, rtol=1e-9, atol=1e-9, name='RVEL')
+    # doppler.turbulence_correction on top of scheme 3 is the same request
+    conf3t = O.make_config(doppler={'scheme': 3, 'turbulence_correction': 1}, **base)
+    eng.configure(conf3t)
+    eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    np.testing.assert_array_equal(eng.ctx.last_spectrum, got)
+
+
+def test_turbulence_spread_vs_oracle():
+    """Scheme 4 (nine sub-beams, each spread with its own eddy dissipation rates) against the CPU restatement;
+    the bins a table term enters from the neighbouring bin (see check_spectrum) are spread out with the rest, so
+    the bar is 2e-6 relative + 2e-4 of the gate's peak."""
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': 4},
+                         radar={'frequency': 5.6, 'radial_resolution': 250., 'PRI': 1000, 'FFT_length': 128,
+                                '3dB_beamwidth': 1.45})
+    eng = make_engine(conf)
+    beams = _beams_with_edr(24, 9, seed=405)
+    _, _, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    got = eng.ctx.last_spectrum
+    luts = util.oracle_luts(1, 5.6)
+    with np.errstate(all='ignore'):
+        want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf, get_refl=O.get_refl_c)
+    want = want_v.values['DSPECTRUM']
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    assert (peak > 0).sum() > 5
+    err = (np.abs(got - want) - 2e-6 * np.abs(want)) / np.maximum(peak, 1e-300)
+    assert err.max() < 2e-4, "gate %d: %.3e of the peak" % (int(err.max(axis=1).argmax()), err.max())
+    np.testing.assert_allclose(got.sum(axis=1), want.sum(axis=1), rtol=2e-4)
+    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=0.02, name='RVEL')
+
+
 def test_doppler_scheme3_needs_one_moment():
     conf = O.make_config(microphysics={'scheme': 2}, doppler={'scheme': 3})
     with pytest.raises(RuntimeError):
@@ -365,6 +436,52 @@ def test_geolocate_vs_oracle():
             n_bad += int((d != 0).sum())
     # float64 libm differences may flip a float32 rounding now and then, never more
     assert n_bad <= 0.001 * geo['dist'].size * 5
+
+
+def test_turbulence_whole_path_and_fallback(capsys):
+    """Scheme 4 through cpol_run_rays.  Without the eddy dissipation rate among the model variables the engine
+    says so and runs the plain spectrum, as the reference's message promises (doppler_sz.py:40-41); with it,
+    EDR is interpolated along the sub-beams like every other variable and each sub-beam's spectrum is spread."""
+    import copy
+    conf = pipeline_conf(1, 3, 3, dscheme=4)
+    conf['radar'].update({'PRI': 1000, 'FFT_length': 128})
+    m = pipeline_model(1)
+    az, el = np.array([10., 200.]), np.array([3.0, 15.0])
+    eng = make_engine(conf)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    assert 'using doppler_scheme == 3 instead' in capsys.readouterr().out
+    eng.set_gauss_hermite()
+    plain = eng.ctx.run_rays(az, el)['dspectrum'].copy()
+    conf3 = copy.deepcopy(conf)
+    conf3['doppler']['scheme'] = 3
+    eng.configure(conf3)
+    np.testing.assert_array_equal(eng.ctx.run_rays(az, el)['dspectrum'], plain)
+    # now with an eddy dissipation rate field
+    eng.configure(conf)
+    fields = dict(m['fields'])
+    z = np.asarray(m['zlev'], dtype=np.float64)
+    fields['EDR'] = (2e-3 * np.exp(-z / 4000.) * (1.5 + np.sin(z / 700.))).astype('float32')
+    eng.upload_model(fields, m['zlev'], m['proj_info'], m['resolution'])
+    out = eng.ctx.run_rays(az, el)
+    assert (out['ray_status'] == 0).all()
+    luts = util.oracle_luts(1, 5.6)
+    attrs = {'z-levels': m['zlev'], 'proj_info': m['proj_info'], 'resolution': m['resolution']}
+    dic = {n: O.ModelVar(a, attrs) for n, a in fields.items()}
+    changed = 0
+    for r in range(len(az)):
+        with np.errstate(all='ignore'):
+            beams = O.get_profiles_GH(dic, az[r], el[r], conf)
+            assert 'EDR' in beams[0].values
+            want_v = O.get_doppler_velocity(beams, luts, conf, get_refl=O.get_refl_c)
+        got, want = out['dspectrum'][r], want_v.values['DSPECTRUM']
+        peak = np.abs(want).max(axis=1, keepdims=True)
+        err = (np.abs(got - want) - 2e-6 * np.abs(want)) / np.maximum(peak, 1e-300)
+        assert err.max() < 2e-4, "ray %d gate %d: %.3e of the peak" % (r, int(err.max(axis=1).argmax()), err.max())
+        # a table term that enters from the neighbouring bin may leave or join the gate's spectrum at its edge
+        np.testing.assert_allclose(got.sum(axis=1), want.sum(axis=1), rtol=2e-4)
+        util.assert_close(out['rvel'][r], want_v.values['RVEL'], rtol=1e-5, atol=0.02, name='RVEL')
+        changed += int((got != plain[r]).sum())
+    assert changed > 100
 
 
 @pytest.mark.parametrize('scheme,nh,nv', [(1, 1, 1), (2, 3, 3)])

@@ -151,3 +151,30 @@ def test_cut_at_sensitivity():
             O.cut_at_sensitivity([b], cfg)
         for k in ('ZH', 'ZDR', 'AH'):
             np.testing.assert_array_equal(b.values[k], g[k + '_' + tag])
+
+
+def test_turbulence_spread_definition():
+    """The turbulence spread the oracle defines (the reference's own is unreachable, doppler_sz.py:36,89, so this
+    is unpinned): Doviak and Zrnic's two regimes with true division, one Gaussian per gate, power kept."""
+    cfg = O.make_config(radar={'radial_resolution': 250., '3dB_beamwidth': 1.45, 'PRI': 1000, 'FFT_length': 128,
+                               'frequency': 5.6})
+    ranges = np.array([125., 5125., 120125., 60125.])
+    edr = np.array([1e-3, 1e-3, 1e-3, 0.])
+    std = O.get_turb_std(ranges, edr, cfg)
+    th = 1.45 * np.pi / 180.
+    # near gates: sigma_r >= 0.1 r sigma_theta (second regime); far gates: first regime
+    assert 250. >= 0.1 * ranges[1] * th and 250. < 0.1 * ranges[2] * th
+    np.testing.assert_allclose(std[2], ((ranges[2] * 1e-3 * th * 1.6 ** 1.5) / 0.72) ** (1. / 3.), rtol=1e-14)
+    want1 = ((1e-3 * 250. * (1.35 * 1.6) ** 1.5) / (11. / 15. + 4. / 15. * (ranges[1] * th / 250.) ** 2) ** (-1.5)) ** (1. / 3.)
+    np.testing.assert_allclose(std[1], want1, rtol=1e-14)
+    assert std[3] == 0.
+    v = O.radar_constants(cfg)['VARRAY']
+    rng = np.random.default_rng(0)
+    spec = rng.uniform(0., 1., (4, len(v))) * (rng.uniform(size=(4, len(v))) < 0.2)
+    out = O.turb_spectrum_spread(spec, std, v)
+    np.testing.assert_allclose(out.sum(axis=1), spec.sum(axis=1), rtol=1e-13)
+    np.testing.assert_array_equal(out[3], spec[3])                     # no turbulence: untouched
+    assert (out[:3] > 0).mean() > (spec[:3] > 0).mean()                # the others are spread out
+    from scipy.ndimage import gaussian_filter1d
+    f = gaussian_filter1d(spec[0], std[0] / (v[2] - v[1]))
+    np.testing.assert_allclose(out[0], f / f.sum() * spec[0].sum(), rtol=1e-14)
