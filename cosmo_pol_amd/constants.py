@@ -18,6 +18,12 @@ KW = 0.93
 A = 1.6                    # Kolmogorov constant of the turbulence spread (constants.py:40)
 RHO_0 = 1.225
 MAX_HEIGHT_COSMO = 35000
+# GPM dual-frequency precipitation radar (constants.py:91-95)
+GPM_SENSITIVITY = 12
+GPM_RADIAL_RES_KA = 250
+GPM_RADIAL_RES_KU = 125
+GPM_NO_BINS_KA = 88 + 1
+GPM_NO_BINS_KU = 176 + 1
 SIMULATED_VARIABLES = ['ZH', 'DSPECTRUM', 'RVEL', 'ZV', 'PHIDP', 'ZDR', 'RHOHV', 'KDP']
 
 
@@ -30,6 +36,8 @@ class Constant_class(object):
         self.A = A
         self.SIMULATED_VARIABLES = SIMULATED_VARIABLES
         self.MAX_HEIGHT_COSMO = MAX_HEIGHT_COSMO
+        self.GPM_SENSITIVITY, self.GPM_RADIAL_RES_KA, self.GPM_RADIAL_RES_KU = GPM_SENSITIVITY, GPM_RADIAL_RES_KA, GPM_RADIAL_RES_KU
+        self.GPM_NO_BINS_KA, self.GPM_NO_BINS_KU = GPM_NO_BINS_KA, GPM_NO_BINS_KU
         self.update()
 
     def update(self):

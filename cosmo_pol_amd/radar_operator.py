@@ -125,6 +125,32 @@ class RadarOperator(object):
                               fixed_angles=sweep_elev if scan_type == 'ppi' else sweep_az,
                               varray=constants.VARRAY)
 
+    def get_GPM_swath(self, GPM_file, band='Ku'):
+        """radar_operator.py:350-424: the swath of a GPM DPR overpass.  GPM_file: the DPR HDF5 file (needs h5py) or
+        a dictionary with the arrays gpm.get_GPM_angles reads.  Returns a gpm.SimulatedGPM."""
+        from . import gpm
+        if not self.dic_vars:
+            print('No model file has been loaded! Aborting...')
+            return None
+        if self.lut_sz is None:
+            raise RuntimeError('lookup tables not set: call set_lut(scheme, lut) first')
+        if band == 'Ku':
+            cfg.CONFIG['radar']['frequency'] = 13.6
+        elif band == 'Ka':
+            cfg.CONFIG['radar']['frequency'] = 35.6
+        cfg.CONFIG['radar']['sensitivity'] = constants.GPM_SENSITIVITY
+        cfg.CONFIG['radar']['type'] = 'GPM'
+        cfg.CONFIG['radar']['radial_resolution'] = constants.GPM_RADIAL_RES_KA if band == 'Ka' \
+            else constants.GPM_RADIAL_RES_KU
+        az, elev, rang, coords_GPM = gpm.get_GPM_angles(GPM_file, band)
+        st = runtime.get_engine(self.device, doppler=0, sensitivity_cut=True)
+        runtime.ensure_luts(st, self.lut_sz)
+        runtime.ensure_model(st, self.dic_vars)
+        beams = gpm.simulate_swath(st.eng, cfg.CONFIG, az, elev, rang, coords_GPM, band)
+        st.conf_snapshot = None              # the engine was reconfigured per scan line
+        st.quad_key = None
+        return gpm.SimulatedGPM(beams, az.shape, band)
+
     def get_PPI(self, elevations, azimuths=[], az_step=-1, az_start=0, az_stop=359):
         """radar_operator.py:195-273."""
         if np.isscalar(elevations):

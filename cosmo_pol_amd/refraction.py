@@ -33,6 +33,24 @@ def ref_4_3(range_vec, elevation_angle, coords_radar):
     return S.astype('float32'), H.astype('float32'), E.astype('float32') * RAD2DEG
 
 
+def get_GPM_refraction(elevation, conf=None):
+    """atm_refraction.py:125-149: gates of a space-borne beam looking down at `elevation` degrees below the
+    horizontal (taken positive), straight propagation (ke = 1) from radar.coords, every radial_resolution up to
+    radar.range.  Only the gates below MAX_HEIGHT_COSMO are returned, so the profiles of two elevations differ
+    in length.  The earth radius is evaluated at coords[0] in degrees used as radians, as the reference does."""
+    from . import cfg, constants
+    r = (conf if conf is not None else cfg.CONFIG)['radar']
+    latitude, altitude_radar = r['coords'][0], r['coords'][2]
+    elev_rad = elevation * DEG2RAD
+    RE = get_earth_radius(latitude)
+    range_vec = np.arange(r['radial_resolution'] / 2., r['range'], r['radial_resolution'])
+    H = -(np.sqrt(range_vec ** 2 + RE ** 2 + 2 * range_vec * RE * np.sin(elev_rad)) - RE) + altitude_radar
+    S = RE * np.arcsin((range_vec * np.cos(elev_rad)) / (RE + H))
+    E = elevation - np.arctan(range_vec * np.cos(elev_rad) / (range_vec * np.sin(elev_rad) + RE + altitude_radar)) * RAD2DEG
+    low = H < constants.MAX_HEIGHT_COSMO
+    return S[low].astype('float32'), H[low].astype('float32'), E[low].astype('float32')
+
+
 def wgs_to_rotated(lat, lon, pole_lat_s, pole_lon_s):
     """Geographic -> rotated-pole coordinates (rlat, rlon) in degrees, pole given by its southern pole as in the
     model's metadata.  Standard rotated-pole transform (pycosmo's own is not part of the reference snapshot)."""

@@ -361,7 +361,11 @@ def integrate_sz(list_beams, luts, cfg):
             if len(N.shape) == 1:
                 N = np.reshape(N, [len(N), 1])
             sz_psd = np.einsum('ijk,ji->ik', sz, N) * dD
-            sz_integ[valid, j, :] = nansum_arr(sz_integ[valid, j, :], sz_psd * beam.GH_weight)
+            # ... and a boolean index shorter than the array (sub-beam shorter than the central one) addressed the
+            # leading part as well
+            sel = np.zeros(len_beams, dtype=bool)
+            sel[:len(valid)] = valid
+            sz_integ[sel, j, :] = nansum_arr(sz_integ[sel, j, :], sz_psd * beam.GH_weight)
     sz_integ = np.nansum(sz_integ, axis=1)
     sz_integ[sz_integ == 0] = np.nan
     return sz_integ
@@ -420,6 +424,51 @@ def ref_4_3(range_vec, elevation_angle, coords_radar):
     S = ke * RE * np.arcsin((range_vec * np.cos(el)) / (ke * RE + H))
     E = el + np.arctan(range_vec * np.cos(el) / (range_vec * np.sin(el) + ke * RE + alt))
     return S.astype('float32'), H.astype('float32'), E.astype('float32') * (180.0 / np.pi)
+
+
+def get_GPM_refraction(elevation, cfg):
+    """refraction/atm_refraction.py:125-149 (space-borne beam, ke = 1, gates below MAX_HEIGHT_COSMO = 35 km only;
+    the earth radius takes coords[0] in degrees as if it were radians, :134)."""
+    r = cfg['radar']
+    latitude, alt = r['coords'][0], r['coords'][2]
+    el = elevation * DEG2RAD
+    RE = get_earth_radius(latitude)
+    rv = np.arange(r['radial_resolution'] / 2., r['range'], r['radial_resolution'])
+    H = -(np.sqrt(rv ** 2 + (1 * RE) ** 2 + 2 * rv * 1 * RE * np.sin(el)) - 1 * RE) + alt
+    S = 1 * RE * np.arcsin((rv * np.cos(el)) / (1 * RE + H))
+    E = elevation - np.arctan(rv * np.cos(el) / (rv * np.sin(el) + 1 * RE + alt)) * (180.0 / np.pi)
+    low = H < 35000
+    return S[low].astype('float32'), H[low].astype('float32'), E[low].astype('float32')
+
+
+def simulated_gpm(list_beams, dim, names):
+    """gpm/GPM_simulator.py:31-88 as loops: (bin_surface, lats, lons, data) of the swath container."""
+    import copy
+    N, M = dim
+    cp = copy.deepcopy(list_beams)
+    bin_surface = np.zeros((N, M))
+    for idx in range(len(cp)):
+        i = int(np.floor(idx / M))
+        j = idx - i * M
+        w = np.where(cp[idx].mask >= 1)[0]
+        bin_surface[i, j] = len(cp[idx].mask) - w[0] if len(w) else 0
+        for k in names:
+            cp[idx].values[k] = cp[idx].values[k][cp[idx].mask < 1]
+        cp[idx].lats_profile = cp[idx].lats_profile[cp[idx].mask < 1]
+        cp[idx].lons_profile = cp[idx].lons_profile[cp[idx].mask < 1]
+    max_len = np.max([len(b.dist_profile) for b in list_beams])
+    data = {k: np.zeros((N, M, max_len)) for k in names}
+    lats = np.zeros((N, M, max_len)) * float('nan')
+    lons = np.zeros((N, M, max_len)) * float('nan')
+    for idx in range(len(cp)):
+        i = int(np.floor(idx / M))
+        j = idx - i * M
+        n = len(cp[idx].values[names[0]])
+        lats[i, j, 0:n] = cp[idx].lats_profile[::-1]
+        lons[i, j, 0:n] = cp[idx].lons_profile[::-1]
+        for k in names:
+            data[k][i, j, 0:n] = cp[idx].values[k][::-1]
+    return bin_surface, lats, lons, data
 
 
 def radar_ranges(cfg):
@@ -837,8 +886,12 @@ def get_profiles_GH(dic_variables, azimuth, elevation, cfg, list_refraction=0):
     list_vars = list(dic_variables.values())
     subs, pts_ver = gh_quadrature(cfg)
     rr = radar_ranges(cfg)
-    refr = list_refraction if list_refraction != 0 else \
-        [ref_4_3(rr, pt + elevation, cfg['radar']['coords']) for pt in pts_ver]
+    if list_refraction != 0:
+        refr = list_refraction
+    elif cfg['radar'].get('type', 'ground') == 'GPM':                       # interpolation.py:254-255
+        refr = [get_GPM_refraction(pt + elevation, cfg) for pt in pts_ver]
+    else:
+        refr = [ref_4_3(rr, pt + elevation, cfg['radar']['coords']) for pt in pts_ver]
     out = []
     for (i, j, ph, pv, w) in subs:
         S, H, E = refr[j]

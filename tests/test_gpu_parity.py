@@ -880,3 +880,88 @@ def test_longer_subbeams_are_truncated_to_the_central_one():
 def cut_all(beams):
     import copy
     return copy.deepcopy(beams)
+
+
+def test_gpm_swath_vs_oracle():
+    """A small GPM swath (2 scan lines x 5 beams, 3 x 3 sub-beams whose profiles differ in length) through
+    gpm.simulate_swath - one call of the ray kernels per scan line with the straight-line profiles uploaded as a
+    refraction table - against the reference's per-beam sequence restated on the CPU (radar_operator.py:379-421:
+    get_profiles_GH with get_GPM_refraction, get_radar_observables, cut_at_sensitivity), then the swath
+    container (GPM_simulator.py:31-88)."""
+    import copy
+    from cosmo_pol_amd import gpm
+    from tests.test_host_cpu import synthetic_dpr
+    d, _ = synthetic_dpr(n_lines=2, n_beams=5, lat0=46.0, lon0=8.5, half_swath=60e3)
+    az, elev, rang, coords = gpm.get_GPM_angles(d, 'Ku')
+    conf = pipeline_conf(1, 3, 3, res=125.)
+    conf['radar'].update({'type': 'GPM', 'frequency': 13.6, 'sensitivity': 12, '3dB_beamwidth': 0.7})
+    m = pipeline_model(1)
+    eng = make_engine(conf)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    beams = gpm.simulate_swath(eng, conf, az, elev, rang, coords, 'Ku')
+    luts = util.oracle_luts(1, 13.6)
+    dic = oracle_model_vars(m)
+    want = []
+    lens = set()
+    for i in range(az.shape[0]):
+        for j in range(az.shape[1]):
+            c = copy.deepcopy(conf)
+            c['radar']['range'] = float(rang[i, j])
+            c['radar']['coords'] = [float(v) for v in coords[i]]
+            with np.errstate(all='ignore'):
+                sub = O.get_profiles_GH(dic, az[i, j], elev[i, j], c)
+                lens.update(len(b.dist_profile) for b in sub)
+                want.append(O.get_radar_observables(sub, luts, c))
+    assert len(lens) > 3                                            # sub-beams of unequal length are exercised
+    with np.errstate(all='ignore'):
+        want = O.cut_at_sensitivity(want, conf)
+    n_finite = 0
+    for idx, (g, w) in enumerate(zip(beams, want)):
+        assert len(g.dist_profile) == len(w.dist_profile), idx
+        obs = np.stack([g.values[n] for n in OBS])
+        check_obs(obs, w.values, 'beam %d' % idx, res_km=0.125)
+        np.testing.assert_array_equal(g.mask, w.mask)
+        np.testing.assert_array_equal(g.dist_profile, w.dist_profile)
+        np.testing.assert_array_equal(g.heights_profile, w.heights_profile)
+        np.testing.assert_allclose(g.lats_profile, w.lats_profile, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(g.lons_profile, w.lons_profile, rtol=0, atol=1e-12)
+        n_finite += int(np.isfinite(w.values['ZH']).sum())
+    assert n_finite > 200
+    sw = gpm.SimulatedGPM(beams, az.shape, 'Ku')
+    bs, lats, lons, data = O.simulated_gpm(want, az.shape, OBS)
+    np.testing.assert_array_equal(sw.bin_surface, bs)
+    np.testing.assert_allclose(sw.lats, lats, rtol=0, atol=1e-12)
+    for n in ('ZH', 'KDP', 'AH'):
+        a, b = sw.data[n], data[n]
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+        ok = ~np.isnan(b)
+        np.testing.assert_allclose(a[ok], b[ok], rtol=2.5e-3 if n == 'ZH' else 1e-5, atol=1e-3 if n == 'KDP' else 0)
+
+
+def test_radar_operator_gpm_swath():
+    """RadarOperator.get_GPM_swath (radar_operator.py:350-424) sets the DPR band's frequency, resolution and
+    sensitivity itself and returns the swath container; its content equals a direct gpm.simulate_swath run."""
+    from cosmo_pol_amd import RadarOperator, gpm, cfg as pcfg
+    from tests.test_host_cpu import synthetic_dpr
+    conf, m, dic, _ = _api_setup(1, 3, 3)
+    tabs = util.synthetic_lut_arrays(1, 13.6)
+    luts = {h: Lookup_table.from_arrays(*t) for h, t in tabs.items()}
+    d, _ = synthetic_dpr(n_lines=1, n_beams=4, lat0=46.0, lon0=8.5, half_swath=50e3)
+    op = RadarOperator(conf)
+    op.load_model_file(dic)
+    op.set_lut(1, luts)
+    sw = op.get_GPM_swath(d, 'Ku')
+    c = pcfg.CONFIG
+    assert c['radar']['type'] == 'GPM' and c['radar']['frequency'] == 13.6 and c['radar']['radial_resolution'] == 125
+    assert sw.data['ZH'].shape[:2] == (1, 4) and sw.band == 'Ku'
+    az, elev, rang, coords = gpm.get_GPM_angles(d, 'Ku')
+    eng = make_engine(c)
+    eng.upload_luts(luts)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    ref = gpm.SimulatedGPM(gpm.simulate_swath(eng, c, az, elev, rang, coords, 'Ku'), az.shape, 'Ku')
+    np.testing.assert_array_equal(sw.bin_surface, ref.bin_surface)
+    for n in OBS:
+        np.testing.assert_array_equal(sw.data[n], ref.data[n])
+    assert np.isfinite(sw.data['ZH']).any() and (sw.bin_surface >= 0).all()
+    # a ground-radar scan afterwards is refused as in the reference (radar_operator.py:159-162)
+    assert op.get_PPI([2.0], az_step=90) == []

@@ -297,3 +297,101 @@ def test_derived_model_variables():
     raw['QV'] = np.full(shp, 0.01)
     wet = model.derive_variables(raw, with_refractivity=True)
     assert wet['N'][0, 0, 0] > out['N'][0, 0, 0] + 40 and wet['RHO'][0, 0, 0] < out['RHO'][0, 0, 0]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# GPM swath geometry and container (gpm/GPM_simulator.py, atm_refraction.py:125-149)
+# ----------------------------------------------------------------------------------------------------------
+def synthetic_dpr(n_lines=2, n_beams=5, lat0=46.0, lon0=8.5, alt=407e3, half_swath=60e3, heading=20.):
+    """A DPR-like geometry: the sub-satellite point advances along `heading`, the footprints of a scan line lie
+    across the track.  The footprints come from the oracle's direct geodesic (Karney), independent of the
+    inverse solution under test."""
+    from cosmo_pol_amd import gpm
+    sc_lat, sc_lon = np.zeros(n_lines), np.zeros(n_lines)
+    lat2, lon2 = np.zeros((n_lines, n_beams)), np.zeros((n_lines, n_beams))
+    az_true = np.zeros((n_lines, n_beams))
+    for i in range(n_lines):
+        lo, la = O.geod_fwd(lon0, lat0, heading, np.array([5000. * i]))
+        sc_lon[i], sc_lat[i] = lo[0], la[0]
+        for j in range(n_beams):
+            d = -half_swath + 2 * half_swath * (j + 0.37) / n_beams          # off-nadir, never exactly below
+            a = heading + (90. if d >= 0 else -90.)
+            lo, la = O.geod_fwd(sc_lon[i], sc_lat[i], a, np.array([abs(d)]))
+            lon2[i, j], lat2[i, j] = lo[0], la[0]
+            az_true[i, j] = a
+    alts = np.full(n_lines, alt)
+    pos = np.stack(gpm.geodetic_to_ecef(sc_lat, sc_lon, alts), axis=1)
+    return {'Latitude': lat2, 'Longitude': lon2, 'scLat': sc_lat, 'scLon': sc_lon, 'dprAlt': alts, 'scPos': pos}, az_true
+
+
+def test_gpm_angles():
+    from cosmo_pol_amd import gpm
+    d, az_true = synthetic_dpr()
+    az, el, rng, coords = gpm.get_GPM_angles(d, 'Ku')
+    assert az.shape == el.shape == rng.shape == (2, 5) and coords.shape == (2, 3)
+    np.testing.assert_allclose((az - az_true + 180.) % 360. - 180., 0., atol=1e-8)
+    np.testing.assert_array_equal(coords[:, 2], d['dprAlt'])
+    # the elevation formula of GPM_simulator.py:221-232 written out for single beams
+    for (i, j) in ((0, 0), (1, 3)):
+        sx, sy, sz = gpm.geodetic_to_ecef(d['Latitude'][i, j], d['Longitude'][i, j], 0.)
+        p = d['scPos'][i]
+        r = np.sqrt((sx - p[0]) ** 2 + (sy - p[1]) ** 2 + (sz - p[2]) ** 2)
+        H = np.sqrt(p[0] ** 2 + p[1] ** 2 + p[2] ** 2)
+        RE = H - d['dprAlt'][i]
+        theta = -np.arcsin((H ** 2 + r ** 2 - RE ** 2) / (2 * H * r)) / np.pi * 180.
+        assert el[i, j] == -theta and rng[i, j] == r
+    # ... and against the true geometry: angle at the satellite between the nadir and the footprint
+    sx, sy, sz = gpm.geodetic_to_ecef(d['Latitude'], d['Longitude'], 0.)
+    los = np.stack([sx, sy, sz], axis=-1) - d['scPos'][:, None, :]
+    nadir = -d['scPos'][:, None, :]
+    cosang = (los * nadir).sum(-1) / np.linalg.norm(los, axis=-1) / np.linalg.norm(nadir, axis=-1)
+    np.testing.assert_allclose(el, 90. - np.degrees(np.arccos(cosang)), atol=0.3)
+    assert (el > 80.).all() and (el < 90.).all()
+    # ECEF: the equator / pole radii and a round trip of the height
+    x, y, z = gpm.geodetic_to_ecef([0., 90.], [0., 0.], [0., 0.])
+    np.testing.assert_allclose([x[0], z[1]], [6378137.0, 6356752.314245], rtol=1e-12)
+
+
+def test_gpm_refraction_equals_oracle():
+    from cosmo_pol_amd import refraction
+    conf = O.make_config(radar={'coords': [46.1, 8.4, 407e3], 'range': 415e3, 'radial_resolution': 125., 'type': 'GPM'})
+    for e in (89.5, 85.0, 81.3, 73.0):
+        conf['radar']['range'] = 407e3 / np.sin(np.radians(e))          # about the distance to the ground
+        got = refraction.get_GPM_refraction(e, conf)
+        want = O.get_GPM_refraction(e, conf)
+        for g, w in zip(got, want):
+            assert g.dtype == np.float32 and g.tobytes() == w.tobytes()
+        S, H, E = got
+        assert 270 <= len(H) <= 360 and H.max() < 35000. and (np.diff(H) < 0).all() and (np.diff(S) > 0).all()
+        assert abs(H.min()) < 6000.                               # the beam ends near the ellipsoid
+    # sub-beams of one GPM ray (same range, different elevations) differ in length
+    conf['radar']['range'] = 412e3
+    assert len(refraction.get_GPM_refraction(85.0, conf)[0]) != len(refraction.get_GPM_refraction(85.7, conf)[0])
+
+
+def test_simulated_gpm_container():
+    from cosmo_pol_amd import gpm
+    from cosmo_pol_amd.beam import Beam
+    rng = np.random.default_rng(3)
+    N, M = 2, 3
+    prod, orc = [], []
+    for idx in range(N * M):
+        n = int(rng.integers(20, 30))
+        mask = np.zeros(n)
+        mask[:2] = -1                               # above the model top
+        nb = int(rng.integers(0, 5))
+        if nb:
+            mask[n - nb:] = 1                        # below the terrain
+        vals = {k: rng.uniform(1., 2., n) for k in ('ZH', 'ZDR')}
+        lat, lon = rng.uniform(45, 46, n), rng.uniform(8, 9, n)
+        dist, hgt = np.arange(n, dtype='float32'), np.arange(n, dtype='float32')[::-1].copy()
+        prod.append(Beam({k: v.copy() for k, v in vals.items()}, mask.copy(), lat.copy(), lon.copy(), dist, hgt))
+        orc.append(O.Beam({k: v.copy() for k, v in vals.items()}, mask.copy(), lat.copy(), lon.copy(), dist, hgt))
+    sw = gpm.SimulatedGPM(prod, (N, M), 'Ku')
+    bs, lats, lons, data = O.simulated_gpm(orc, (N, M), ['ZH', 'ZDR'])
+    np.testing.assert_array_equal(sw.bin_surface, bs)
+    np.testing.assert_array_equal(sw.lats, lats)
+    np.testing.assert_array_equal(sw.lons, lons)
+    for k in data:
+        np.testing.assert_array_equal(sw.data[k], data[k])
+    assert sw.band == 'Ku' and gpm.get_group('Ka') == 'HS'
