@@ -55,10 +55,16 @@ class RadarOperator(object):
         return {'latitude': c[0], 'longitude': c[1], 'altitude': c[2], 'time': t}
 
     def load_model_file(self, filename, cfilename=''):
-        """filename: path of an .npz written by cosmo_pol_amd.model.save_npz, or an already built
-        {name: ModelVariable} dictionary.  The microphysics scheme follows the variables present
-        (radar_operator.py:124-132)."""
-        dic = filename if isinstance(filename, dict) else model_mod.load_npz(filename)
+        """filename: path of an .npz written by cosmo_pol_amd.model.save_npz, of a NetCDF file of the model (.nc,
+        classic format), or an already built {name: ModelVariable} dictionary.  The microphysics scheme follows
+        the variables present (radar_operator.py:124-132); the refractivity is derived when refraction scheme 2
+        is configured (:94-96)."""
+        if isinstance(filename, dict):
+            dic = filename
+        elif str(filename).endswith(('.nc', '.nc3', '.cdf')):
+            dic = model_mod.load_netcdf(filename, with_refractivity=cfg.CONFIG['refraction']['scheme'] == 2)
+        else:
+            dic = model_mod.load_npz(filename)
         missing = [v for v in BASE_VARIABLES if v not in dic]
         if missing:
             raise ValueError('Not all necessary variables could be found in file: missing %s' % missing)

@@ -395,3 +395,49 @@ def test_simulated_gpm_container():
     for k in data:
         np.testing.assert_array_equal(sw.data[k], data[k])
     assert sw.band == 'Ku' and gpm.get_group('Ka') == 'HS'
+
+
+def test_model_from_netcdf(tmp_path):
+    """model.load_netcdf: half-level heights and W to full levels, contents per volume, rotated-pole metadata,
+    and RadarOperator.load_model_file choosing the moment scheme from the species present."""
+    from scipy.io import netcdf_file
+    from cosmo_pol_amd import model, RadarOperator
+    rng = np.random.default_rng(11)
+    nz, ny, nx = 6, 5, 7
+    path = str(tmp_path / 'lfff00000000.nc')
+    hhl = np.linspace(12000., 400., nz + 1)[:, None, None] + rng.uniform(0, 50, (1, ny, nx))
+    raw = {'P': 1e5 * np.exp(-0.5 * (hhl[:-1] + hhl[1:]) / 8000.), 'T': rng.uniform(230, 290, (nz, ny, nx)),
+           'QV': rng.uniform(0, 5e-3, (nz, ny, nx)), 'U': rng.normal(size=(nz, ny, nx)), 'V': rng.normal(size=(nz, ny, nx)),
+           'W': rng.normal(size=(nz + 1, ny, nx)), 'QR': rng.uniform(0, 1e-3, (nz, ny, nx)),
+           'QS': rng.uniform(0, 1e-3, (nz, ny, nx)), 'QG': rng.uniform(0, 1e-3, (nz, ny, nx)),
+           'QC': rng.uniform(0, 1e-4, (nz, ny, nx)), 'EDR': rng.uniform(0, 1e-2, (nz, ny, nx))}
+    with netcdf_file(path, 'w') as f:
+        for d, n in (('time', 1), ('level', nz), ('level1', nz + 1), ('rlat', ny), ('rlon', nx)):
+            f.createDimension(d, n)
+        f.createVariable('rlon', 'f8', ('rlon',))[:] = -1.0 + 0.02 * np.arange(nx)
+        f.createVariable('rlat', 'f8', ('rlat',))[:] = 0.5 + 0.02 * np.arange(ny)
+        rp = f.createVariable('rotated_pole', 'c', ())
+        rp.grid_north_pole_latitude = 43.0
+        rp.grid_north_pole_longitude = -170.0
+        f.createVariable('HHL', 'f4', ('time', 'level1', 'rlat', 'rlon'))[0] = hhl
+        for k, a in raw.items():
+            lev = 'level1' if a.shape[0] == nz + 1 else 'level'
+            f.createVariable(k, 'f4', ('time', lev, 'rlat', 'rlon'))[0] = a
+    dic = model.load_netcdf(path, with_refractivity=True)
+    assert set(dic) == {'U', 'V', 'W', 'T', 'RHO', 'QR_v', 'QS_v', 'QG_v', 'EDR', 'N'}
+    at = dic['T'].attributes
+    assert at['proj_info']['Latitude_of_southern_pole'] == -43.0 and at['proj_info']['Longitude_of_southern_pole'] == 10.0
+    np.testing.assert_allclose([at['proj_info'][k] for k in ('Lo1', 'La1', 'Lo2', 'La2')], [-1.0, 0.5, -0.88, 0.58])
+    np.testing.assert_allclose(at['resolution'], [0.02, 0.02])
+    h32 = hhl.astype('float32').astype('float64')
+    np.testing.assert_allclose(at['z-levels'], 0.5 * (h32[:-1] + h32[1:]), rtol=1e-7)
+    f32 = lambda a: np.asarray(a, dtype='float32').astype('float64')
+    np.testing.assert_allclose(dic['W'].data, 0.5 * (f32(raw['W'])[:-1] + f32(raw['W'])[1:]), rtol=1e-6, atol=1e-7)
+    rho = model.air_density(f32(raw['P']), f32(raw['T']), f32(raw['QV']),
+                            f32(raw['QC']) + f32(raw['QR']) + f32(raw['QS']) + f32(raw['QG']))
+    np.testing.assert_allclose(dic['RHO'].data, rho, rtol=1e-6)
+    np.testing.assert_allclose(dic['QS_v'].data, f32(raw['QS']) * rho, rtol=1e-6)
+    assert dic['EDR'].data.dtype == np.float32 and dic['N'].data.shape == (nz, ny, nx)
+    op = RadarOperator(O.make_config())
+    op.load_model_file(path)
+    assert op.current_microphys_scheme == 1 and 'EDR' in op.dic_vars and 'QH_v' not in op.dic_vars
