@@ -113,7 +113,8 @@ def main():
     ap.add_argument('--cpu-rays', type=int, default=1440)
     ap.add_argument('--cpu-cores', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--doppler', type=int, choices=[0, 1, 2], default=2, help='doppler.scheme of the workload')
+    ap.add_argument('--doppler', type=int, choices=[0, 1, 2, 3], default=2,
+                    help='doppler.scheme of the workload (3 = full Doppler spectrum, needs --microphysics 1)')
     ap.add_argument('--microphysics', type=int, choices=[1, 2], default=2,
                     help='2 = the headline 2-moment workload; 1 = the same volume with 1-moment input (3 classes)')
     ap.add_argument('--gh', type=int, default=3, help='Gauss-Hermite nodes per direction: 3 = the 9 sub-beams of the headline '

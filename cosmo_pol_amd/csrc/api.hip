@@ -159,7 +159,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->refr_tab) (void)hipFree(ctx->refr_tab);
     if (ctx->rawptr_dev) (void)hipFree((void *)ctx->rawptr_dev);
     for (auto &l : ctx->lut) {
-        float *owned[] = {l.raw, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
+        float *owned[] = {l.raw, l.rcs, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
         for (float *q : owned) if (q) (void)hipFree(q);
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -263,7 +263,7 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
         return fail(ctx, CPOL_ERR_ARG, "bad psd descriptor");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     LutDev &L = ctx->lut[cls];
-    float **owned[] = {&L.raw, &L.table, &L.xq, &L.table_dop, &L.xq_dop, &L.d_axis};
+    float **owned[] = {&L.raw, &L.rcs, &L.table, &L.xq, &L.table_dop, &L.xq_dop, &L.d_axis};
     for (float **q : owned) if (*q) { HIPCHK(ctx, hipFree(*q)); }
     L = LutDev();
     size_t nt = (size_t)lut->n_e * lut->n_t * lut->n_d * CPOL_N_SZ;
@@ -554,9 +554,19 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
     if (ctx->cfg.doppler_scheme == 3) {
         if (ctx->n_vel < 2) return fail(ctx, CPOL_ERR_STATE, "doppler_scheme 3: cpol_set_velocity_bins has not been called");
-        // device array of the raw-table / diameter-axis pointers of the three classes
+        // the spectrum needs the radar cross-section only: 4 KB per table node instead of the 48 KB of all twelve
+        // components, built once per uploaded table
+        for (int h = 0; h < 3; h++) {
+            LutDev &L = ctx->lut[h];
+            if (!L.rcs) {
+                const long n = (long)L.n_e * L.n_t * 1024;
+                HIPCHK(ctx, hipMalloc((void **)&L.rcs, n * sizeof(float)));
+                launch_build_rcs(ctx->stream, L.raw, L.rcs, n);
+            }
+        }
+        // device array of the cross-section table / diameter-axis pointers of the three classes
         const float *hp[2 * CPOL_MAX_CLASSES] = {nullptr};
-        for (int h = 0; h < 3; h++) { hp[h] = ctx->lut[h].raw; hp[CPOL_MAX_CLASSES + h] = ctx->lut[h].d_axis; }
+        for (int h = 0; h < 3; h++) { hp[h] = ctx->lut[h].rcs; hp[CPOL_MAX_CLASSES + h] = ctx->lut[h].d_axis; }
         if (!ctx->rawptr_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->rawptr_dev, sizeof(hp)));
         HIPCHK(ctx, hipMemcpyAsync((void *)ctx->rawptr_dev, hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // hp is a stack buffer
@@ -580,6 +590,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
             sp.d_min[h] = (float)pd.d_min; sp.d_max[h] = (float)pd.d_max; sp.step[h] = ctx->lut[h].dD;
             sp.inv_alpha[h] = 1.0 / pd.alpha; sp.inv_beta[h] = 1.0 / pd.beta;
             sp.mu[h] = (float)pd.mu; sp.nu[h] = (float)pd.nu;
+            sp.geo_step[h] = (ctx->lut[h].axis_uniform && (float)pd.nu == 1.f) ? ctx->lut[h].axis_step : 0.;
         }
         launch_spectrum(ctx->stream, ct, sp, nr, nu, vals, plane, elev, mask, wsub, phi, ctx->varray_dev,
                         ctx->rawptr_dev, ctx->rawptr_dev + CPOL_MAX_CLASSES, spectrum, rvel_out, ray0);

@@ -19,6 +19,7 @@ struct LutDev {
     float  e_min = 0, e_step = 1, t_min = 0, t_step = 1;
     float  dD = 0;                 // D[1]-D[0] in float32 (scattering_sz.py:50)
     float *raw = nullptr;          // [n_e][n_t][1024][12] as uploaded
+    float *rcs = nullptr;          // [n_e][n_t][1024] radar cross-section 2 pi (z0 - z1 - z2 + z3), built for the Doppler spectrum
     float *table = nullptr;        // [n_e][n_t] slices of 1024 x ncol, permuted and pre-multiplied by D^mu (see k_integrate)
     float *xq = nullptr;           // D^nu, permuted for the integrate kernel's ds_read_b128
     float *table_dop = nullptr;    // compact 3-column image of the separate Doppler units (k_integrate_dop)
@@ -120,7 +121,7 @@ struct cpol_ctx {
     int turb = 0;                  // turbulence broadening of the spectrum
     double turb_beamwidth = 0., turb_a = 1.6;
     double *varray_dev = nullptr;
-    const float **rawptr_dev = nullptr;   // [2][CPOL_MAX_CLASSES]: raw tables, diameter axes
+    const float **rawptr_dev = nullptr;   // [2][CPOL_MAX_CLASSES]: cross-section tables, diameter axes
     int n_refr = 0;                       // refraction table (cpol_set_refraction_table)
     double *refr_keys = nullptr;
     float *refr_tab = nullptr;            // [3][n_refr][n_gates]: S, H, E
@@ -181,6 +182,7 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
                           const double *n0d, float2 *dop_out, long slot0, unsigned long long *work);
+void launch_build_rcs(hipStream_t s, const float *raw, float *rcs, long n);
 void launch_build_dop_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                             double mu_d, double nu_d, double alpha_d, double beta_d, double x_ref);
 struct SpecParams {
@@ -189,6 +191,7 @@ struct SpecParams {
     float  d_min[3], d_max[3], step[3];
     double inv_alpha[3], inv_beta[3];   // get_D_from_V: (1/alpha * v)^(1/beta)
     float  mu[3], nu[3];
+    double geo_step[3];            // diameter step when nu = 1 on an equally spaced axis, else 0
     // turbulence broadening (off when turb == 0)
     int    turb;
     double sigma_r, sigma_theta;   // radial resolution [m], 3 dB beamwidth [rad]
