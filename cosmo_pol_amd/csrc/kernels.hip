@@ -1760,9 +1760,14 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                 double *__restrict__ spectrum, double *__restrict__ rvel, long ray0)
 {
     extern __shared__ double sm[];
-    double *term = sm;                       // [3][1024]
-    double *acc = sm + 3 * 1024;             // [n_vel]
+    // One class at a time goes through LDS (8 KB of terms instead of 24): the kernel is a chain of dependent
+    // float additions per velocity bin, so what counts is how many wavefronts a CU can hold to overlap them.
+    double *term = sm;                       // [1024] terms of the class in hand; with turbulence [3072]: weights and convolved bins
+    double *acc = sm + (sp.turb ? 3 * 1024 : 1024);      // [n_vel]
     double *bs = acc + sp.n_vel;             // [n_vel] one sub-beam's weighted spectrum (turbulence broadening only)
+    // per velocity bin: diameter index range [ia, ib) per class, float accumulator of the bin's reflectivity
+    struct BinRec { short ia[3], ib[3]; float refl; };
+    BinRec *rec = (BinRec *)(acc + sp.n_vel * (sp.turb ? 2 : 1));
     const int lane = threadIdx.x;
     const int G = sp.n_gates, B = sp.n_sub, NV = sp.n_vel;
     const int r = blockIdx.x / G, g = blockIdx.x % G;
@@ -1784,51 +1789,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
             psd_params(p, q, 0.f, Tp, &l, &n0);
             if (q == 0.f) l = __builtin_nan("");
             lam32[jc] = (float)l; n032[jc] = (float)n0;
-            // terms of the class at the table node nearest to (elevation, temperature)
-            const LutView &lv = ct.lut[jc];
-            int ie = nearest_node(e_lut, lv.e_min, lv.e_step, lv.n_e);
-            int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
-            const float *sl = rcs_tab[jc] + (long)(ie * lv.n_t + it) * 1024;
-            const bool on = lam32[jc] > 0.f;
-            const double lamd = (double)lam32[jc];
-            const float muj = sp.mu[jc];
-            if (sp.geo_step[jc] > 0.) {
-                // nu = 1 on an equally spaced axis: a lane's diameters are 64 steps apart, so its exponentials
-                // form a geometric sequence, E(D_0 + 64 i step) = E(D_0) R^i: two exponentials per lane and class
-                // instead of sixteen.  The axis values are float32 roundings of the ideal ones; the difference
-                // delta enters to first order, exp(-lambda (D + delta)) = exp(-lambda D) (1 - lambda delta), the
-                // second order being below 1e-10 for |lambda delta| < 1e-5.
-                const double D0 = (double)d_axis[jc][0] + (double)lane * sp.geo_step[jc];
-                double E = on ? exp(-lamd * D0) : 0.;
-                const double R = on ? exp(-lamd * 64. * sp.geo_step[jc]) : 0.;
-                for (int i = 0; i < 16; i++) {
-                    const int k = lane + 64 * i;
-                    double t = 0.;
-                    if (on) {
-                        const float rcs = sl[k];
-                        const double D = (double)d_axis[jc][k];
-                        const double delta = D - (D0 + (double)(64 * i) * sp.geo_step[jc]);
-                        const double dm = muj == 0.f ? 1. : (muj == 1.f ? D : (muj == 0.5f ? sqrt(D) : pow(D, (double)muj)));
-                        t = dm * (E - E * (lamd * delta)) * (double)rcs;
-                        E *= R;
-                    }
-                    term[jc * 1024 + k] = t;
-                }
-            } else {
-                for (int k = lane; k < 1024; k += 64) {
-                    double t = 0.;
-                    if (on) {
-                        const float rcs = sl[k];
-                        double D = (double)d_axis[jc][k];
-                        double dm = muj == 0.f ? 1. : (muj == 1.f ? D : pow(D, (double)muj));
-                        double dn = sp.nu[jc] == 1.f ? D : pow(D, (double)sp.nu[jc]);
-                        t = dm * exp(-lamd * dn) * (double)rcs;
-                    }
-                    term[jc * 1024 + k] = t;
-                }
-            }
         }
-        __syncthreads();
         // fall speed at the velocity bins (doppler_sz.py:337-346), NumPy promotion kept
         const float rho = vals[(long)CPOL_V_RHO * plane + u], rho0 = vals[(long)CPOL_V_RHO * plane + rb * G];
         const float rinv = 1.0f / sqrtf(rho / rho0);
@@ -1841,44 +1802,98 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
         const double hor = (Uw * phi_sc[2 * rb] + Vw * phi_sc[2 * rb + 1]) / (double)(float)tan((double)th);
         const double sth = (double)(float)sin((double)th);
         const double w = wsub[b];
-        if (sp.turb) {
-            for (int i = lane; i < NV; i += 64) bs[i] = 0.;
-            __syncthreads();
+        // diameter interval of every velocity bin and class
+        for (int i = lane; i < NV; i += 64) {
+            BinRec br;
+            for (int jc = 0; jc < 3; jc++) { br.ia[jc] = -1; br.ib[jc] = -1; }      // -1: the class adds nothing to this bin
+            br.refl = 0.f;
+            if (i < NV - 1) {
+                double wh0 = (double)rinv * (Ww + hor - varray[i] / sth);
+                double wh1 = (double)rinv * (Ww + hor - varray[i + 1] / sth);
+                if (wh0 >= 0 && wh1 >= 0) {
+                    float Da[3], Db[3];
+                    bool keep = false;
+                    for (int jc = 0; jc < 3; jc++) {
+                        // (v / alpha)^(1 / beta) through exp(y log x): the float32 rounding hides its 1e-15
+                        float d0 = (float)powxy(sp.inv_alpha[jc] * wh0, sp.inv_beta[jc]);
+                        float d1 = (float)powxy(sp.inv_alpha[jc] * wh1, sp.inv_beta[jc]);
+                        // the reference clips the whole matrix with each later class's limits (:355-357)
+                        for (int jl = jc; jl < 3; jl++) {
+                            if (d0 >= sp.d_max[jl]) d0 = sp.d_max[jl];
+                            if (d0 <= sp.d_min[jl]) d0 = sp.d_min[jl];
+                            if (d1 >= sp.d_max[jl]) d1 = sp.d_max[jl];
+                            if (d1 <= sp.d_min[jl]) d1 = sp.d_min[jl];
+                        }
+                        Da[jc] = fminf(d0, d1); Db[jc] = fmaxf(d0, d1);
+                        keep = keep || (Db[jc] - Da[jc]) != 0.0f;
+                    }
+                    if (keep) {
+                        for (int jc = 0; jc < 3; jc++) {
+                            if (lam32[jc] > 0.f) {
+                                int ia = (int)((Da[jc] - sp.d_min[jc]) / sp.step[jc]);
+                                int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
+                                br.ia[jc] = (short)min(max(ia, 0), 1024);
+                                br.ib[jc] = (short)min(max(ib, 0), 1024);
+                            }
+                        }
+                    }
+                }
+            }
+            rec[i] = br;
         }
-        for (int i = lane; i < NV - 1; i += 64) {
-            double wh0 = (double)rinv * (Ww + hor - varray[i] / sth);
-            double wh1 = (double)rinv * (Ww + hor - varray[i + 1] / sth);
-            if (!(wh0 >= 0) || !(wh1 >= 0)) continue;
-            float Da[3], Db[3];
-            bool keep = false;
-            for (int jc = 0; jc < 3; jc++) {
-                // (v / alpha)^(1 / beta) through exp(y log x): the float32 rounding hides its 1e-15
-                float d0 = (float)powxy(sp.inv_alpha[jc] * wh0, sp.inv_beta[jc]);
-                float d1 = (float)powxy(sp.inv_alpha[jc] * wh1, sp.inv_beta[jc]);
-                // the reference clips the whole matrix with each later class's limits (:355-357)
-                for (int jl = jc; jl < 3; jl++) {
-                    if (d0 >= sp.d_max[jl]) d0 = sp.d_max[jl];
-                    if (d0 <= sp.d_min[jl]) d0 = sp.d_min[jl];
-                    if (d1 >= sp.d_max[jl]) d1 = sp.d_max[jl];
-                    if (d1 <= sp.d_min[jl]) d1 = sp.d_min[jl];
+        for (int jc = 0; jc < 3; jc++) {
+            if (!(lam32[jc] > 0.f)) continue;                 // wave-uniform: the class adds nothing (doppler_c.c:20)
+            // terms of the class at the table node nearest to (elevation, temperature)
+            const LutView &lv = ct.lut[jc];
+            int ie = nearest_node(e_lut, lv.e_min, lv.e_step, lv.n_e);
+            int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
+            const float *sl = rcs_tab[jc] + (long)(ie * lv.n_t + it) * 1024;
+            const double lamd = (double)lam32[jc];
+            const float muj = sp.mu[jc];
+            __syncthreads();                                  // the previous class's sums have read term[]
+            if (sp.geo_step[jc] > 0.) {
+                // nu = 1 on an equally spaced axis: a lane's diameters are 64 steps apart, so its exponentials
+                // form a geometric sequence, E(D_0 + 64 i step) = E(D_0) R^i: two exponentials per lane and class
+                // instead of sixteen.  The axis values are float32 roundings of the ideal ones; the difference
+                // delta enters to first order, exp(-lambda (D + delta)) = exp(-lambda D) (1 - lambda delta), the
+                // second order being below 1e-10 for |lambda delta| < 1e-5.
+                const double D0 = (double)d_axis[jc][0] + (double)lane * sp.geo_step[jc];
+                double E = exp(-lamd * D0);
+                const double R = exp(-lamd * 64. * sp.geo_step[jc]);
+                for (int i = 0; i < 16; i++) {
+                    const int k = lane + 64 * i;
+                    const float rcs = sl[k];
+                    const double D = (double)d_axis[jc][k];
+                    const double delta = D - (D0 + (double)(64 * i) * sp.geo_step[jc]);
+                    const double dm = muj == 0.f ? 1. : (muj == 1.f ? D : (muj == 0.5f ? sqrt(D) : pow(D, (double)muj)));
+                    term[k] = dm * (E - E * (lamd * delta)) * (double)rcs;
+                    E *= R;
                 }
-                Da[jc] = fminf(d0, d1); Db[jc] = fmaxf(d0, d1);
-                keep = keep || (Db[jc] - Da[jc]) != 0.0f;
+            } else {
+                for (int k = lane; k < 1024; k += 64) {
+                    const float rcs = sl[k];
+                    double D = (double)d_axis[jc][k];
+                    double dm = muj == 0.f ? 1. : (muj == 1.f ? D : pow(D, (double)muj));
+                    double dn = sp.nu[jc] == 1.f ? D : pow(D, (double)sp.nu[jc]);
+                    term[k] = dm * exp(-lamd * dn) * (double)rcs;
+                }
             }
-            if (!keep) continue;
-            float refl = 0.f;
-            for (int jc = 0; jc < 3; jc++) {
-                if (lam32[jc] > 0.f) {
-                    int ia = (int)((Da[jc] - sp.d_min[jc]) / sp.step[jc]);
-                    int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
+            __syncthreads();
+            // the reference's float accumulator per bin (doppler_c.c:24-26), classes in order
+            for (int i = lane; i < NV - 1; i += 64) {
+                const int ia = rec[i].ia[jc], ib = rec[i].ib[jc];
+                if (ia >= 0) {
                     float sum = 0.f;
-                    for (int k = ia; k < ib; k++) sum = (float)((double)sum + term[jc * 1024 + k]);
-                    refl += sum * sp.step[jc] * n032[jc];
+                    for (int k = ia; k < ib; k++) sum = (float)((double)sum + term[k]);
+                    rec[i].refl += sum * sp.step[jc] * n032[jc];
                 }
             }
-            refl *= sp.zfac;
-            if (sp.turb) bs[i] = (double)refl * w;
-            else acc[i] += (double)refl * w;
+        }
+        __syncthreads();
+        if (sp.turb) {
+            for (int i = lane; i < NV; i += 64) bs[i] = (double)(rec[i].refl * sp.zfac) * w;
+        } else {
+            for (int i = lane; i < NV; i += 64) acc[i] += (double)(rec[i].refl * sp.zfac) * w;
         }
         __syncthreads();
         if (sp.turb) {
@@ -1950,7 +1965,7 @@ void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, 
                      const double *varray, const float *const *raw, const float *const *d_axis, double *spectrum,
                      double *rvel, long ray0)
 {
-    size_t lds = (size_t)(3 * 1024 + sp.n_vel * (sp.turb ? 2 : 1)) * sizeof(double);
+    size_t lds = (size_t)((sp.turb ? 3 * 1024 : 1024) + sp.n_vel * (sp.turb ? 2 : 1)) * sizeof(double) + (size_t)sp.n_vel * 16;
     hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((long)n_rays * sp.n_gates)), dim3(64), lds, s, ct, sp, nu, vals, plane,
                        elev, mask, wsub, phi_sc, varray, raw, d_axis, spectrum, rvel, ray0);
 }
