@@ -1752,7 +1752,7 @@ void launch_build_rcs(hipStream_t s, const float *raw, float *rcs, long n)
 // (3) the GH-weighted bin values are accumulated in float64.  Three classes (rain, snow,
 // graupel), as the reference's get_refl hard-wires.
 // =============================================================================
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64, 3)
 void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float *__restrict__ vals, long plane,
                 const float *__restrict__ elev, const signed char *__restrict__ mask, const double *__restrict__ wsub,
                 const double *__restrict__ phi_sc, const double *__restrict__ varray,
