@@ -518,7 +518,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const long max_chunks = (nu * ct.n_cls + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb_pol;
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
-    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
+    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_cbkt.p, (int *)ctx->b_sorted.p,
                      (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p, ctx->timing ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {

@@ -7,7 +7,7 @@
 #include "../../include/cosmopol.h"
 
 #define CPOL_WAVE 64
-#define CPOL_CHUNK_UNITS 256      // units (gate x sub-beam x class) per integrate workgroup
+#define CPOL_CHUNK_UNITS 512      // units (gate x sub-beam x class) per integrate workgroup
 #define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_LINE_N 32            // doubles per (ray, sub-beam) record of the geodesic line constants
@@ -177,7 +177,7 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
+                      const int *chunk_off, const int *chunk_bucket, int *sorted, const float2 *lam, float *psd_out,
                       unsigned long long *work);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,

@@ -998,19 +998,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out,
+                 const int *__restrict__ chunk_bucket, int *sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out,
                  unsigned long long *__restrict__ work)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
     constexpr int LDS_X = SLICE_FLOATS + 64;
-    static_assert(CPOL_CHUNK_UNITS == INTEG_THREADS, "the chunk-local sort handles one unit per thread");
+    static_assert(CPOL_CHUNK_UNITS == 2 * INTEG_THREADS, "the chunk-local sort handles two units per thread");
     __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 64 + 1024];
     // chunk-local counting sort of the units by the number of quads (16 diameters) their N(D) survives
     // (its 65 counters borrow the start of the table area, which is filled only afterwards: with them in a
     // region of their own the workgroup would pass the LDS size at which three fit a CU)
+    // The sorted order itself replaces the chunk's segment of the unit list in global memory (every thread reads
+    // its entries before any is rewritten): the list's order inside a chunk means nothing to its other reader,
+    // k_integrate_dop, which orders the units itself.
     int *s_hist = (int *)lds;
-    __shared__ unsigned char s_perm[CPOL_CHUNK_UNITS];      // unit (index in the chunk) at each sorted position
 
     // XCD-aware chunk order: the workgroups of one XCD (blockIdx % 8) take runs of INTEG_XCD_RUN consecutive
     // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2; the runs go round the XCDs
@@ -1039,22 +1041,28 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
     if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 68) s_hist[tid] = 0;
-    float2 lu = make_float2(0.f, 0.f);
-    if (tid < cnt) lu = lam[sorted[start + tid]];
+    int myslot[2] = {0, 0};
+    float2 lu[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+        if (tid + t * INTEG_THREADS < cnt) { myslot[t] = sorted[start + tid + t * INTEG_THREADS]; lu[t] = lam[myslot[t]]; }
     __syncthreads();
 
     // ---- order the chunk's units by where their N(D) becomes an exact float32 zero ----
     // nqu = number of quads whose first D^nu does not exceed the unit's cutoff (bisection over 64 ascending values)
-    int nqu = 64;
-    if (cut_ok) {
-        const float xc = psd_cutoff_x(lu.x + lu.y);
-        nqu = 0;
+    int nqu[2] = {64, 64}, myrank[2] = {0, 0};
 #pragma unroll
-        for (int step = 64; step >= 1; step >>= 1)
-            if (nqu + step <= 64 && lds[LDS_X + (nqu + step - 1) * 16] <= xc) nqu += step;
+    for (int t = 0; t < 2; t++) {
+        if (cut_ok) {
+            const float xc = psd_cutoff_x(lu[t].x + lu[t].y);
+            int c = 0;
+#pragma unroll
+            for (int step = 64; step >= 1; step >>= 1)
+                if (c + step <= 64 && lds[LDS_X + (c + step - 1) * 16] <= xc) c += step;
+            nqu[t] = c;
+        }
+        if (tid + t * INTEG_THREADS < cnt) myrank[t] = atomicAdd(&s_hist[nqu[t]], 1);
     }
-    int myrank = 0;
-    if (tid < cnt) myrank = atomicAdd(&s_hist[nqu], 1);
     __syncthreads();
     if (wave == 0) {
         const int h = s_hist[lane];
@@ -1070,10 +1078,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     }
     __syncthreads();
     const int nq_chunk = s_hist[65];
-    if (tid < cnt) {
-        const int pos = s_hist[nqu] + myrank;
-        s_perm[pos] = (unsigned char)tid;
-    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+        if (tid + t * INTEG_THREADS < cnt) sorted[start + s_hist[nqu[t]] + myrank[t]] = myslot[t];
     __syncthreads();
 
     // ---- stage the quads the chunk needs: straight 16-byte copy of the pre-permuted image ----
@@ -1119,8 +1126,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         int ua = g0 * 16 + j, ub = ua + 16;
         // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
         float2 la = make_float2(0.f, 0.f), lb = la;
-        if (ua < cnt) la = lam[sorted[start + s_perm[ua]]];
-        if (ub < cnt) lb = lam[sorted[start + s_perm[ub]]];
+        if (ua < cnt) la = lam[sorted[start + ua]];
+        if (ub < cnt) lb = lam[sorted[start + ub]];
         const f32x2 nhi = {-la.x, -lb.x}, nlo = {-la.y, -lb.y};
         double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
         // quads up to the last one in which any of the pass's units still has a nonzero float32 N(D): the count
@@ -1233,8 +1240,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 // result rows of 16 floats (the spare columns hold zeros): one aligned 64-byte write per unit,
                 // wherever the cutoff order scattered the pass's units over the slots
                 constexpr int ROW = CPOL_N_COL;
-                if (u0 < cnt) psd_out[(long)sorted[start + s_perm[u0]] * ROW + j] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)sorted[start + s_perm[u1]] * ROW + j] = (float)db[r];
+                if (u0 < cnt) psd_out[(long)sorted[start + u0] * ROW + j] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)sorted[start + u1] * ROW + j] = (float)db[r];
             }
         }
     }
@@ -1244,7 +1251,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 }
 
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam, float *psd_out,
+                      const int *chunk_off, const int *chunk_bucket, int *sorted, const float2 *lam, float *psd_out,
                       unsigned long long *work)
 {
     if (max_chunks <= 0) return;
@@ -1295,7 +1302,8 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 {
     __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
     __shared__ int s_hist[68];
-    __shared__ unsigned char s_perm[CPOL_CHUNK_UNITS], s_nq[CPOL_CHUNK_UNITS];
+    __shared__ unsigned short s_perm[CPOL_CHUNK_UNITS];
+    __shared__ unsigned char s_nq[CPOL_CHUNK_UNITS];
     const int c_lo = chunk_off[b_lo];
     const unsigned total = (unsigned)(chunk_off[b_hi] - c_lo);
     // runs of INTEG_XCD_RUN consecutive chunks go round the XCDs, as in k_integrate
@@ -1363,7 +1371,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int i = tid + t * DOP_THREADS;
-        if (i < cnt) { const int pos = s_hist[nqu[t]] + myrank[t]; s_perm[pos] = (unsigned char)i; s_nq[pos] = (unsigned char)nqu[t]; }
+        if (i < cnt) { const int pos = s_hist[nqu[t]] + myrank[t]; s_perm[pos] = (unsigned short)i; s_nq[pos] = (unsigned char)nqu[t]; }
     }
     __syncthreads();
     // a wavefront takes 128 consecutive positions of that order, a lane positions p and p + 64 of them
