@@ -7,7 +7,7 @@
 #include "../../include/cosmopol.h"
 
 #define CPOL_WAVE 64
-#define CPOL_CHUNK_UNITS 512      // units (gate x sub-beam x class) per integrate workgroup
+#define CPOL_CHUNK_UNITS 1024      // units (gate x sub-beam x class) per integrate workgroup
 #define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_LINE_N 32            // doubles per (ray, sub-beam) record of the geodesic line constants

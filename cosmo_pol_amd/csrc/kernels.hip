@@ -1004,7 +1004,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
     constexpr int LDS_X = SLICE_FLOATS + 64;
-    static_assert(CPOL_CHUNK_UNITS == 2 * INTEG_THREADS, "the chunk-local sort handles two units per thread");
+    constexpr int UPT = CPOL_CHUNK_UNITS / INTEG_THREADS;       // units per thread in the chunk-local sort
+    static_assert(CPOL_CHUNK_UNITS == UPT * INTEG_THREADS, "whole units per thread");
     __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 64 + 1024];
     // chunk-local counting sort of the units by the number of quads (16 diameters) their N(D) survives
     // (its 65 counters borrow the start of the table area, which is filled only afterwards: with them in a
@@ -1041,18 +1042,21 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
     if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 68) s_hist[tid] = 0;
-    int myslot[2] = {0, 0};
-    float2 lu[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    int myslot[UPT];
+    float2 lu[UPT];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < UPT; t++) {
+        myslot[t] = 0; lu[t] = make_float2(0.f, 0.f);
         if (tid + t * INTEG_THREADS < cnt) { myslot[t] = sorted[start + tid + t * INTEG_THREADS]; lu[t] = lam[myslot[t]]; }
+    }
     __syncthreads();
 
     // ---- order the chunk's units by where their N(D) becomes an exact float32 zero ----
     // nqu = number of quads whose first D^nu does not exceed the unit's cutoff (bisection over 64 ascending values)
-    int nqu[2] = {64, 64}, myrank[2] = {0, 0};
+    int nqu[UPT], myrank[UPT];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < UPT; t++) {
+        nqu[t] = 64; myrank[t] = 0;
         if (cut_ok) {
             const float xc = psd_cutoff_x(lu[t].x + lu[t].y);
             int c = 0;
@@ -1079,7 +1083,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     __syncthreads();
     const int nq_chunk = s_hist[65];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < UPT; t++)
         if (tid + t * INTEG_THREADS < cnt) sorted[start + s_hist[nqu[t]] + myrank[t]] = myslot[t];
     __syncthreads();
 
@@ -1328,7 +1332,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         const float4 *src = (const float4 *)(lv.table + (long)(ie * lv.n_t + it) * CPOL_DOP_SLICE);
         float4 *dst = (float4 *)lds;
 #pragma unroll
-        for (int i = 0; i < CPOL_DOP_SLICE / 4 / DOP_THREADS; i++) dst[tid + i * DOP_THREADS] = src[tid + i * DOP_THREADS];
+        for (int i = tid; i < CPOL_DOP_SLICE / 4; i += DOP_THREADS) dst[i] = src[i];
     }
     if (tid < 68) s_hist[tid] = 0;
     __syncthreads();
