@@ -987,7 +987,7 @@ void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#define INTEG_THREADS 256
+#define INTEG_THREADS 512
 #define INTEG_XCD_RUN 16         // consecutive chunks per XCD before the next XCD's run
 
 // Table image (global and LDS alike, built by k_build_image):
@@ -996,7 +996,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // j = lane & 15 < NC) finds its four B operands in one 16-byte word.  NC = 12 (three
 // workgroups per CU) or 14 with the two Doppler scheme-2 moments (two per CU).
 template <int NC>
-__global__ __launch_bounds__(INTEG_THREADS, NC == 12 ? 3 : 2)
+__global__ __launch_bounds__(INTEG_THREADS, (NC == 12 ? 3 : 2) * (INTEG_THREADS / 256))
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                  const int *__restrict__ chunk_bucket, int *sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out,
                  unsigned long long *__restrict__ work)
@@ -1039,7 +1039,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int lane = tid & 63, wave = tid >> 6;
 
     // ---- D^nu first: it decides how much of the slice the chunk needs ----
-    ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
+    if (tid < 256) ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
     if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 68) s_hist[tid] = 0;
     int myslot[UPT];
@@ -1095,7 +1095,6 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         const int n4 = ((nq_chunk + 3) & ~3) * 4 * NC;
         constexpr int PER = SLICE_FLOATS / 4 / INTEG_THREADS;
         static_assert(SLICE_FLOATS % (4 * INTEG_THREADS) == 0, "slice must be a whole number of 16-byte rounds");
-        static_assert(PER % 2 == 0, "rounds are issued in pairs");
         // whole rounds of one 16-byte word per thread (the last one may reach past n4, never past the slice),
         // two loads in flight per thread
         const int rounds = (n4 + INTEG_THREADS - 1) / INTEG_THREADS;
@@ -1121,8 +1120,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 
     // passes of 32 units in cutoff order; the four waves take them in snake order (0 1 2 3 3 2 1 0 ...) so
     // that every wave gets cheap and expensive ones
-    for (int r4 = 0; r4 * 4 < npass; r4++) {
-        const int ps = r4 * 4 + ((r4 & 1) ? 3 - wave : wave);
+    constexpr int NW = INTEG_THREADS / 64;
+    for (int r4 = 0; r4 * NW < npass; r4++) {
+        const int ps = r4 * NW + ((r4 & 1) ? NW - 1 - wave : wave);
         if (ps >= npass) continue;
         const int g0 = ps * 2;
         // two groups of 16 units per pass: two independent accumulators, and the two units'
@@ -1250,7 +1250,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         }
     }
     if (work) {                                       // wave-uniform count of evaluated unit x quad steps
-        if (lane == 0) atomicAdd(&work[(blockIdx.x * 4 + wave) & 63], (unsigned long long)wsum);
+        if (lane == 0) atomicAdd(&work[(blockIdx.x * NW + wave) & 63], (unsigned long long)wsum);
     }
 }
 
