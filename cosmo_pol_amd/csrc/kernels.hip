@@ -1118,7 +1118,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int npass = (cnt + 31) >> 5;
     unsigned wsum = 0;
 
-    // passes of 32 units in cutoff order; the four waves take them in snake order (0 1 2 3 3 2 1 0 ...) so
+    // passes of 32 units in cutoff order; the waves take them in snake order (0 1 2 ... 7 7 6 ... 0 ...) so
     // that every wave gets cheap and expensive ones
     constexpr int NW = INTEG_THREADS / 64;
     for (int r4 = 0; r4 * NW < npass; r4++) {
@@ -1298,7 +1298,7 @@ __device__ inline void dop_unit_plain(const float *lds, float2 l, int nq8, doubl
     *o12 = s12; *o13 = s13;
 }
 
-__global__ __launch_bounds__(DOP_THREADS)
+__global__ __launch_bounds__(DOP_THREADS, 6)
 void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                      const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, const float2 *__restrict__ lam,
                      const double *__restrict__ n0d, float2 *__restrict__ dop_out, long slot0,
