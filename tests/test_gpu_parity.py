@@ -86,6 +86,37 @@ def test_observables_vs_oracle(scheme, n_gates, n_sub, att, dscheme):
     util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
 
 
+@pytest.mark.parametrize('n_units', [1, 31, 33, 1023, 1024, 1025, 2049])
+def test_one_bucket_with_chunk_boundary_counts(n_units):
+    """All units of a class in a single (elevation, temperature) node, their number straddling the integration
+    kernels' pass (32) and chunk (1024) sizes: every gate has its own lambda, so the chunk-local cutoff order
+    permutes them, and the last chunk is a single unit or one short of full."""
+    # (no attenuation correction: over 2049 gates of heavy precipitation the reference's float32 cumprod drifts
+    # from the float64 scan by more than the bar, which is beside the point here)
+    conf = O.make_config(microphysics={'scheme': 2}, attenuation={'correction': 0}, doppler={'scheme': 2},
+                         radar={'frequency': 5.6})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(n_units, 1, 2, seed=900 + n_units, zero_frac=0., nan_tail=0, below_head=0)
+    rng = np.random.default_rng(n_units)
+    b = beams[0]
+    b['values']['T'][:] = 268.3
+    b['elev'][:] = 3.1
+    for h in 'RSGH':
+        q = (10. ** rng.uniform(-6., -3., n_units)).astype('float32')
+        lo, hi = syn.X_RANGE[h]
+        b['values']['Q%s_v' % h][:] = q
+        b['values']['QN%s_v' % h][:] = (q / np.exp(rng.uniform(np.log(lo), np.log(hi), n_units))).astype('float32')
+    assert all((b['values'][k] > 0).all() for k in ('QR_v', 'QS_v', 'QG_v', 'QH_v'))
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    luts = util.oracle_luts(2, 5.6)
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
+        want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf)
+    check_obs(obs, want.values, 'bucket of %d' % n_units)
+    util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
+    assert np.isfinite(obs[0]).all()
+
+
 @pytest.mark.parametrize('scheme,dscheme', [(1, 0), (1, 2), (2, 2)])
 def test_observables_with_extreme_contents(scheme, dscheme):
     """Mass and number densities scaled over 10 decades: the slope parameter of the size distributions then
