@@ -477,7 +477,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const long nslots = nu * n_planes;
     const int nb = n_planes * ct.ne_max * ct.nt_max;
     const int nb_pol = ct.n_cls * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
-    TRY(ensure(ctx, ctx->b_key, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->b_key, nslots * sizeof(cpol_key_t)));
     TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
     TRY(ensure(ctx, ctx->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
@@ -494,10 +494,10 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
     launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
-                (int *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
+                (cpol_key_t *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
                 (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
     launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->b_cbkt.p);
-    launch_scatter(ctx->stream, nu, ct.n_cls, (const int *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
+    launch_scatter(ctx->stream, nu, ct.n_cls, (const cpol_key_t *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
                    (int *)ctx->b_sorted.p);
     }
     if (ctx->timing) {
@@ -595,7 +595,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         launch_spectrum(ctx->stream, ct, sp, nr, nu, vals, plane, elev, mask, wsub, phi, ctx->varray_dev,
                         ctx->rawptr_dev, ctx->rawptr_dev + CPOL_MAX_CLASSES, spectrum, rvel_out, ray0);
     }
-    launch_observables(ctx->stream, op, nr, nu, (const int *)ctx->b_key.p, (const double *)ctx->b_coef.p,
+    launch_observables(ctx->stream, op, nr, nu, (const cpol_key_t *)ctx->b_key.p, (const double *)ctx->b_coef.p,
                        (const float *)ctx->b_psd.p, mask, wsub, (const double *)ctx->b_vr.p, obs, obs_plane, ray0,
                        mask_out, rvel_out, d2, spectrum, ctx->n_vel);
     HIPCHK(ctx, hipGetLastError());

@@ -8,6 +8,7 @@
 
 #define CPOL_WAVE 64
 #define CPOL_CHUNK_UNITS 1024      // units (gate x sub-beam x class) per integrate workgroup
+typedef short cpol_key_t;         // bucket (class, elevation node, temperature node) of a unit, -1 = not valid; at most 16384 buckets
 #define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_LINE_N 32            // doubles per (ray, sub-beam) record of the geodesic line constants
@@ -166,7 +167,7 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
                    float *vals, long plane, signed char *mask, float *raw_out);
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                  const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
-                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, double *n0d,
+                 const double *phi_sc, int doppler, cpol_key_t *key, int *rank, float2 *lam, double *coef, double *n0d,
                  int *hist, double *vr);
 void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                         int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
@@ -174,7 +175,7 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
                  int *chunk_bucket);
-void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *offs,
+void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, int *sorted, const float2 *lam, float *psd_out,
@@ -217,7 +218,7 @@ struct Dop2In {                    // inputs of the Doppler scheme-2 reduction i
     const float *xq[CPOL_MAX_CLASSES];
     int n_t[CPOL_MAX_CLASSES];
 };
-void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
+void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const cpol_key_t *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel);

@@ -761,7 +761,7 @@ __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
 __global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
                        const float *__restrict__ elev, const signed char *__restrict__ /*mask: invalid gates carry NaN*/,
                        const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
-                       int *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
+                       cpol_key_t *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
                        double *__restrict__ coef, double *__restrict__ n0d, int *__restrict__ hist,
                        double *__restrict__ vr)
 {
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_g
             coef[(long)h * nu + u] = n0 * (double)lv.dD * w * f0;
             if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = n0 * f0;
         }
-        if (live) key[(long)h * nu + u] = k;
+        if (live) key[(long)h * nu + u] = (cpol_key_t)k;
         // position of the unit inside its (bucket, shard) counter: one atomic per run of equal keys
         int hl, len;
         wave_run(k, lane, &hl, &len);
@@ -875,7 +875,7 @@ void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc)
 
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                  const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
-                 const double *phi_sc, int doppler, int *key, int *rank, float2 *lam, double *coef, double *n0d,
+                 const double *phi_sc, int doppler, cpol_key_t *key, int *rank, float2 *lam, double *coef, double *n0d,
                  int *hist, double *vr)
 {
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, ct, nu, n_gates, vals, plane,
@@ -953,7 +953,7 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 
 // Final position of every valid polarimetric unit = bucket start + start of its shard inside the bucket + the
 // rank k_prep drew.
-__global__ void k_scatter(long nu, const int *__restrict__ key, const int *__restrict__ rank,
+__global__ void k_scatter(long nu, const cpol_key_t *__restrict__ key, const int *__restrict__ rank,
                           const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -965,7 +965,7 @@ __global__ void k_scatter(long nu, const int *__restrict__ key, const int *__res
     sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
 }
 
-void launch_scatter(hipStream_t s, long nu, int n_cls, const int *key, const int *rank, const int *offs,
+void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted)
 {
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_cls), dim3(256), 0, s, nu, key, rank, offs, cursor,
@@ -1493,7 +1493,7 @@ __device__ inline double wave_scan_incl(double x, int lane)
 // Doppler scheme 2 (doppler_sz.py:155-231) for one (ray, sub-beam, gate): RCS- and PSD-weighted mean fall
 // speed over the classes from the two extra columns of the PSD integration, unit-spacing trapezoid rule
 // (sum minus half of the end terms, :219-220), air-density correction and projection on the beam (:23,231).
-__device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict__ key, const float *__restrict__ psd_out,
+__device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__restrict__ key, const float *__restrict__ psd_out,
                                          long nu, long u, long rb, int G)
 {
     double vh = 0., nn = 0.;
@@ -1536,7 +1536,7 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const int *__restrict
 
 // Stage 1, one thread per (ray, gate): sub-beam and class sums, observables without the range scans.
 __global__ __launch_bounds__(256, 6)
-void k_gate_reduce(ObsParams op, int n_rays, long nu, const int *__restrict__ key, const double *__restrict__ coef,
+void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
                    long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2)
@@ -1672,7 +1672,7 @@ void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0
     }
 }
 
-void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const int *key,
+void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const cpol_key_t *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel)
