@@ -114,9 +114,13 @@ extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters,
     return CPOL_OK;
 }
 
+static int fail(cpol_ctx *ctx, int code, const char *msg);
+
 extern "C" int cpol_set_batch_units(cpol_ctx *ctx, long max_units)
 {
     if (!ctx || max_units < 1) return CPOL_ERR_ARG;
+    // unit slots (2 kinds x classes x positions) are addressed with 32-bit integers
+    if (max_units > (128L << 20)) return fail(ctx, CPOL_ERR_ARG, "at most 128 Mi positions per batch");
     ctx->max_batch_units = (size_t)max_units;
     return CPOL_OK;
 }

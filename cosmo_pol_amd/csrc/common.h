@@ -133,7 +133,7 @@ struct cpol_ctx {
     Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
         b_sorted, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
         o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
-    size_t max_batch_units = (size_t)16 << 20;     // (ray x sub-beam x gate) positions per batch
+    size_t max_batch_units = (size_t)32 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
     unsigned long long *work_dev = nullptr;       // 2 x 64 partial counts of unit x 16-diameter steps evaluated by k_integrate / k_integrate_dop (timing only)
     bool timing = false;

@@ -121,7 +121,8 @@ int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_l
  * stage INTEGRATE_DOP, where a unit whose N0 is an exact zero needs no term at all. */
 int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters);
 /* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
- * workspace the library allocates (default 16 Mi positions, about 13 GB with 2-moment input and Doppler scheme 2). */
+ * workspace the library allocates (default 32 Mi positions, about 26 GB with 2-moment input and Doppler scheme 2,
+ * allocated only as far as a call needs it; at most 128 Mi). */
 int cpol_set_batch_units(cpol_ctx *ctx, long max_units);
 
 /* ---- state -------------------------------------------------------------------------- */

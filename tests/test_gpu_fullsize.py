@@ -95,7 +95,7 @@ def test_batching_and_ray_order_do_not_matter(volume):
     try:
         out2 = eng.ctx.run_rays(volume['azs'][perm], volume['elv'][perm])
     finally:
-        eng.ctx.set_batch_units(16 << 20)
+        eng.ctx.set_batch_units(32 << 20)
     for k in ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height'):
         a = out[k][:, perm] if k == 'obs' else out[k][perm]
         b = out2[k]
