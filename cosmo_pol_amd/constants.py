@@ -50,6 +50,12 @@ class Constant_class(object):
         self.VARRAY = np.arange(-self.NVEL, self.NVEL + self.VRES, self.VRES)
         self.WAVELENGTH = C / (r['frequency'] * 1E09) * 1000
         self.PULSE_WIDTH = 2 * r['radial_resolution']
+        sens = r.get('sensitivity')
+        if isinstance(sens, (list, tuple)) and len(sens) == 3:
+            # radar equation after Probert-Jones (constants.py:79-82)
+            self.RADAR_CONSTANT_DB = 180 - 10 * np.log10(np.pi ** 3 * r['3dB_beamwidth'] ** 2
+                                                         * self.KW ** 2 * self.PULSE_WIDTH / 1000) - 2 * sens[1] \
+                + 10 * np.log10(1024 * np.log(2) * (self.WAVELENGTH / 1000.) ** 2)
         if r['type'] == 'ground':
             self.RANGE_RADAR = np.arange(r['radial_resolution'] / 2, r['range'], r['radial_resolution'])
 

@@ -189,6 +189,7 @@ extern "C" int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg)
     if (!ctx || !cfg) return CPOL_ERR_ARG;
     if (cfg->n_gates <= 0 || cfg->range_res <= 0) return fail(ctx, CPOL_ERR_ARG, "n_gates and range_res must be positive");
     if (cfg->microphysics_scheme != 1 && cfg->microphysics_scheme != 2) return fail(ctx, CPOL_ERR_ARG, "microphysics_scheme must be 1 or 2");
+    if (cfg->sensitivity_mode < 0 || cfg->sensitivity_mode > 3) return fail(ctx, CPOL_ERR_ARG, "sensitivity_mode must be 0, 1, 2 or 3");
     if (cfg->doppler_scheme < 0 || cfg->doppler_scheme > 3)
         return fail(ctx, CPOL_ERR_ARG, "doppler_scheme must be 0 (off), 1, 2 or 3");
     if (cfg->doppler_scheme == 3 && cfg->microphysics_scheme != 1)

@@ -1476,20 +1476,10 @@ void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, 
 // =============================================================================
 // per-ray reduction: GH-weighted sub-beam sum with the reference's float32 storage
 // (scattering_sz.py:38,105), class sum (:109-110), observables (:164-196), the two
-// range scans (:117-125) as wavefront prefix scans, mask (:144-151), Doppler
+// range scans (:117-125) as wavefront scans in the reference's float32 order, mask (:144-151), Doppler
 // scheme 1/2 averaging (doppler_sz.py:62-87), sensitivity cut (utilities.py:68-105).
 // Two kernels: k_gate_reduce (one thread per gate) and k_ray_scan (one wavefront per ray).
 // =============================================================================
-__device__ inline double wave_scan_incl(double x, int lane)
-{
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double t = __shfl_up(x, off);
-        if (lane >= off) x += t;
-    }
-    return x;
-}
-
 // Doppler scheme 2 (doppler_sz.py:155-231) for one (ray, sub-beam, gate): RCS- and PSD-weighted mean fall
 // speed over the classes from the two extra columns of the PSD integration, unit-spacing trapezoid rule
 // (sum minus half of the end terms, :219-220), air-density correction and projection on the beam (:23,231).
@@ -1610,7 +1600,38 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     if (rvel_out && (op.doppler == 1 || op.doppler == 2)) rvel_out[o] = rv / sw;
 }
 
-// Stage 2, one wavefront per ray: PHIDP and the attenuation as prefix scans along range, sensitivity cut.
+// Inclusive float32 running sum / product over the 64 lanes of a wavefront in the reference's order:
+// acc_i = fl(acc_{i-1} (op) x_i), one rounding per gate, exactly what np.cumsum / np.cumprod do on a float32
+// array (utilities.py:18-24).  Every lane walks the wave's 64 values (v_readlane, no LDS) and stops taking
+// part after its own; `carry` is the value before lane 0 and returns as the value after lane 63.
+__device__ inline float wave_seq_sum(float x, int lane, float &carry)
+{
+    float acc = carry;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
+        const float t = acc + v;
+        acc = i <= lane ? t : acc;
+    }
+    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+    return acc;
+}
+
+__device__ inline float wave_seq_prod(float x, int lane, float &carry)
+{
+    float acc = carry;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
+        const float t = acc * v;
+        acc = i <= lane ? t : acc;
+    }
+    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+    return acc;
+}
+
+// Stage 2, one wavefront per ray: PHIDP and the attenuation as sequential float32 scans along range (the
+// reference's accumulation order and precision), sensitivity cut.
 __global__ __launch_bounds__(64)
 void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0,
                 double *__restrict__ rvel_out, double *__restrict__ spectrum, int n_vel)
@@ -1618,7 +1639,7 @@ void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0
     const int r = blockIdx.x, lane = threadIdx.x;
     const int G = op.n_gates;
     const float qnan = __builtin_nanf("");
-    double carry_phi = 0, carry_h = 0, carry_v = 0;
+    float carry_phi = 0.f, carry_h = 1.f, carry_v = 1.f;
     for (int g0 = 0; g0 < G; g0 += 64) {
         const int g = g0 + lane;
         const bool act = g < G;
@@ -1626,30 +1647,33 @@ void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0
         float zh = obs[CPOL_O_ZH * obs_plane + o], zv = obs[CPOL_O_ZV * obs_plane + o];
         const float kdpm = obs[CPOL_O_KDP * obs_plane + o];
         const float ah = obs[CPOL_O_AH * obs_plane + o], av = obs[CPOL_O_AV * obs_plane + o];
-        // PHIDP = cumsum(nan->0 of 2*KDP_m) * res / 1000
-        float two_k = 2.f * kdpm;
-        double xphi = (act && two_k == two_k) ? (double)two_k : 0.;
-        double sc = wave_scan_incl(xphi, lane) + carry_phi;
-        carry_phi = __shfl(sc, 63);
-        float phidp = (float)sc * op.res / 1000.f;
+        // PHIDP = nan_cumsum(2 * KDP_m) * res / 1000  (scattering_sz.py:118)
+        const float two_k = 2.f * kdpm;
+        const float sc = wave_seq_sum((act && two_k == two_k) ? two_k : 0.f, lane, carry_phi);
+        const float phidp = sc * op.res / 1000.f;
         bool att = false;
         float zdr = 0.f;
         if (op.att_corr) {
-            // cumprod(nan->1 of 10^(-0.1*A*res_km)) = 10^(cumsum of the exponents)
-            float eh = (-0.1f * ah) * op.res_km, ev = (-0.1f * av) * op.res_km;
-            double xh = (act && eh == eh) ? (double)eh : 0., xv = (act && ev == ev) ? (double)ev : 0.;
-            double sh = wave_scan_incl(xh, lane) + carry_h, sv = wave_scan_incl(xv, lane) + carry_v;
-            carry_h = __shfl(sh, 63); carry_v = __shfl(sv, 63);
-            zv *= (float)exp10(sv);
-            zh *= (float)exp10(sh);
+            // ZV *= nan_cumprod(10 ** (-0.1 * AV * res_km)), the same for ZH  (scattering_sz.py:120-123)
+            // the factor is the correctly rounded float32 power (float64 evaluation, one rounding), what a libm
+            // powf returns; NumPy's vectorised float32 power differs from it in the last bit for 10-20 % of
+            // arguments, depending on the CPU it runs on
+            const float fh = (float)exp10((double)((-0.1f * ah) * op.res_km));
+            const float fv = (float)exp10((double)((-0.1f * av) * op.res_km));
+            const float ph = wave_seq_prod((act && fh == fh) ? fh : 1.f, lane, carry_h);
+            const float pv = wave_seq_prod((act && fv == fv) ? fv : 1.f, lane, carry_v);
+            zv *= pv;
+            zh *= ph;
             zdr = zh / zv;
             att = true;
         }
         bool cut = false;
         if (op.sens_mode && act) {
+            // utilities.py:74-81; mode 3 carries sensitivity + radar constant + SNR as one number
             double thr;
             if (op.sens_mode == 1) thr = op.sens0;
-            else thr = (op.sens0 - 20 * log10(op.sens1 / 1000.)) + 20 * log10((op.res_d * g) / 1000.);
+            else if (op.sens_mode == 2) thr = (op.sens0 - 20 * log10(op.sens1 / 1000.)) + 20 * log10((op.res_d * g) / 1000.);
+            else thr = op.sens0 + 20 * log10((op.res_d * g) / 1000.);
             float zdb = 10.f * log10f(zh);
             cut = (double)zdb < thr;
         }

@@ -47,8 +47,20 @@ class Engine(object):
         if not isinstance(sens, (list, tuple)):
             sens = [sens]
         mode = 0
+        sens = [float(v) for v in sens]
         if sensitivity_cut:
-            mode = len(sens) if len(sens) in (1, 2) else 0
+            if len(sens) not in (1, 2, 3):
+                # the reference prints this and returns the beams uncut (utilities.py:83-88)
+                print('Sensitivity parameters are invalid, cannot cut at specified sensitivity')
+            else:
+                mode = len(sens)
+            if mode == 3:
+                # [sensitivity (dBm), gain (dBm), SNR (dB)]: threshold = sensitivity + RADAR_CONSTANT_DB + SNR
+                # + 20 log10(r / 1000) (utilities.py:74-76, constants.py:79-82)
+                pulse_width = 2 * r['radial_resolution']
+                rc_db = 180 - 10 * np.log10(np.pi ** 3 * r['3dB_beamwidth'] ** 2 * cst.KW ** 2 * pulse_width / 1000) \
+                    - 2 * sens[1] + 10 * np.log10(1024 * np.log(2) * (wl / 1000.) ** 2)
+                sens = [float(sens[0] + rc_db + sens[2]), 0.]
         self.ctx.set_config(radar_lat=float(r['coords'][0]), radar_lon=float(r['coords'][1]),
                             radar_alt=float(r['coords'][2]), range_res=float(r['radial_resolution']),
                             earth_radius=float(earth_radius(r['coords'][1])), n_gates=len(rr),

@@ -37,6 +37,9 @@ def sensitivity_threshold(ranges):
     if not isinstance(sens, list):
         sens = [sens]
     with np.errstate(divide='ignore'):
+        if len(sens) == 3:
+            from .constants import constants
+            return sens[0] + constants.RADAR_CONSTANT_DB + sens[2] + 20 * np.log10(ranges / 1000.)
         if len(sens) == 2:
             return (sens[0] - 20 * np.log10(sens[1] / 1000.)) + 20 * np.log10(ranges / 1000.)
         if len(sens) == 1:
@@ -52,6 +55,7 @@ def cut_at_sensitivity(list_beams):
         rr = cfg.CONFIG['radar']['radial_resolution'] * np.arange(len(b.dist_profile))
         thr = sensitivity_threshold(rr)
         if thr is None:
+            print('Sensitivity parameters are invalid, cannot cut at specified sensitivity')
             return
         with np.errstate(all='ignore'):
             m = 10 * np.log10(b.values['ZH']) < thr

@@ -59,7 +59,10 @@ typedef struct {
     int    attenuation_correction;            /* attenuation.correction */
     int    microphysics_scheme;               /* 1 or 2 */
     int    doppler_scheme;                    /* 0 = skip, 1, 2, 3 (3 needs cpol_set_velocity_bins and 1-moment input) */
-    int    sensitivity_mode;                  /* 0 = no cut, 1 = scalar, 2 = [ZH, range] (utilities.py:74-81) */
+    int    sensitivity_mode;                  /* 0 = no cut, 1 = [ZH], 2 = [ZH, range], 3 = [sensitivity, gain, SNR]
+                                                 (utilities.py:74-81).  Mode 3: sensitivity[0] = sensitivity +
+                                                 constants.RADAR_CONSTANT_DB (constants.py:80-82) + SNR, summed in
+                                                 that order by the caller */
     double sensitivity[2];
 } cpol_config;
 

@@ -381,9 +381,19 @@ def combined_mask(list_beams, len_beams):
     return mask
 
 
-def get_radar_observables(list_beams, luts, cfg):
+def pow10_rounded(x):
+    """10 ** x for a float32 array as the correctly rounded float32 value (what a libm powf returns).  NumPy's
+    own float32 power is vectorised on AVX-512 hosts and then differs from this in the last bit for 10-20 % of
+    arguments, so the reference's attenuation factors depend on the CPU it runs on."""
+    return (10. ** np.asarray(x, dtype=np.float64)).astype(np.float32)
+
+
+def get_radar_observables(list_beams, luts, cfg, pow10=None):
     """scatter/scattering_sz.py:17-161.  Mutates its inputs like the reference
-    (truncation :56-57, elevation folding :61-68)."""
+    (truncation :56-57, elevation folding :61-68).  pow10: how 10 ** x of the attenuation factors (:121-122) is
+    evaluated; None = NumPy's float32 power as in the reference, or pow10_rounded."""
+    if pow10 is None:
+        pow10 = lambda x: 10 ** x
     consts = radar_constants(cfg)
     res = cfg['radar']['radial_resolution']
     idx_0 = int(len(list_beams) / 2)
@@ -393,8 +403,8 @@ def get_radar_observables(list_beams, luts, cfg):
     KDP_m = KDP + DELTA_HV
     PHIDP = nan_cumsum(2 * KDP_m) * res / 1000.
     if cfg['attenuation']['correction']:
-        ZV *= nan_cumprod(10 ** (-0.1 * AV * (res / 1000.)))
-        ZH *= nan_cumprod(10 ** (-0.1 * AH * (res / 1000.)))
+        ZV *= nan_cumprod(pow10(-0.1 * AV * (res / 1000.)))
+        ZH *= nan_cumprod(pow10(-0.1 * AH * (res / 1000.)))
         ZDR = ZH / ZV
     obs = {'ZH': ZH, 'ZDR': ZDR, 'ZV': ZV, 'KDP': KDP_m, 'DELTA_HV': DELTA_HV,
            'PHIDP': PHIDP, 'RHOHV': RHOHV, 'AH': AH, 'AV': AV}
@@ -755,7 +765,15 @@ def cut_at_sensitivity(beams, cfg):
     sens = cfg['radar']['sensitivity']
     if not isinstance(sens, list):
         sens = [sens]
-    if len(sens) == 2:
+    if len(sens) == 3:
+        # constants.py:77-82 (RADAR_CONSTANT_DB, Probert-Jones) and utilities.py:74-76
+        r_ = cfg['radar']
+        wl = radar_constants(cfg)['WAVELENGTH']
+        pulse_width = 2 * r_['radial_resolution']
+        rc_db = 180 - 10 * np.log10(np.pi ** 3 * r_['3dB_beamwidth'] ** 2 * KW ** 2 * pulse_width / 1000) \
+            - 2 * sens[1] + 10 * np.log10(1024 * np.log(2) * (wl / 1000.) ** 2)
+        thr = lambda r: sens[0] + rc_db + sens[2] + 20 * np.log10(r / 1000.)
+    elif len(sens) == 2:
         thr = lambda r: (sens[0] - 20 * np.log10(sens[1] / 1000.)) + 20 * np.log10(r / 1000.)
     elif len(sens) == 1:
         thr = lambda r: sens[0]

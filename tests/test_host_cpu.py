@@ -441,3 +441,30 @@ def test_model_from_netcdf(tmp_path):
     op = RadarOperator(O.make_config())
     op.load_model_file(path)
     assert op.current_microphys_scheme == 1 and 'EDR' in op.dic_vars and 'QH_v' not in op.dic_vars
+
+
+def test_cut_at_sensitivity_three_elements_vs_oracle():
+    """radar.sensitivity = [sensitivity, gain, SNR]: utilities.cut_at_sensitivity thresholds with the radar
+    constant of constants.py:79-82 (utilities.py:74-76); the oracle restates the same and the closed form is
+    checked against a hand evaluation."""
+    from cosmo_pol_amd import utilities
+    from cosmo_pol_amd.beam import Beam
+    from cosmo_pol_amd.constants import constants
+    conf = O.make_config(radar={'sensitivity': [-85., 42., 8.], 'radial_resolution': 500., 'range': 20000.,
+                                'frequency': 5.6, '3dB_beamwidth': 1.45})
+    cfg.set_config(conf)
+    constants.update()
+    wl = 299792458. / 5.6e9 * 1000
+    want_rc = 180 - 10 * np.log10(np.pi ** 3 * 1.45 ** 2 * 0.93 ** 2 * 1000. / 1000) - 2 * 42. \
+        + 10 * np.log10(1024 * np.log(2) * (wl / 1000.) ** 2)
+    assert constants.RADAR_CONSTANT_DB == want_rc
+    rng = np.random.default_rng(3)
+    zh = (10 ** rng.uniform(-2, 4, 40)).astype('float32')
+    mine = Beam({'ZH': zh.copy(), 'KDP': zh.copy(), 'AH': zh.copy()}, np.zeros(40), None, None, np.zeros(40), np.zeros(40))
+    ob = O.Beam({'ZH': zh.copy(), 'KDP': zh.copy(), 'AH': zh.copy()}, np.zeros(40), None, None, np.zeros(40), np.zeros(40))
+    utilities.cut_at_sensitivity([mine])
+    O.cut_at_sensitivity([ob], conf)
+    for k in ('ZH', 'KDP', 'AH'):
+        np.testing.assert_array_equal(mine.values[k], ob.values[k])
+    n_cut = int(np.isnan(mine.values['ZH']).sum())
+    assert 0 < n_cut < 40 and not np.isnan(mine.values['AH']).any()
