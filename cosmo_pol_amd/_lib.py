@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcosmopol_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_DOMAIN, ERR_REFRACTION = 0, 1, 2, 3, 4, 5
 N_OBS = 9
+STATIC_MAX_POSITIONS = 65536
 OBS_NAMES = ['ZH', 'ZDR', 'ZV', 'KDP', 'DELTA_HV', 'PHIDP', 'RHOHV', 'AH', 'AV']
 VAR_SLOTS = {'U': 0, 'V': 1, 'W': 2, 'QR_v': 3, 'QS_v': 4, 'QG_v': 5, 'RHO': 6, 'T': 7,
              'QH_v': 8, 'QNH_v': 9, 'QNR_v': 10, 'QNS_v': 11, 'QNG_v': 12, 'EDR': 13}
@@ -56,7 +57,7 @@ class CpolOutputs(C.Structure):
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
            'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
-           'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_geolocate', 'cpol_interp_points',
+           'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_run_rays_static', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
 _lib = None
@@ -93,6 +94,7 @@ def load():
     lib.cpol_set_refraction_table.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_float_p, c_float_p]
     lib.cpol_run_rays.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_run_rays_dev.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
+    lib.cpol_run_rays_static.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_geolocate.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p, c_double_p, c_float_p, c_int_p]
     lib.cpol_interp_points.argtypes = [vp, C.c_int, c_float_p, c_float_p, c_float_p]
@@ -296,6 +298,14 @@ class Context(object):
         o = outputs if outputs is not None else CpolOutputs()
         rc = self.lib.cpol_run_rays_dev(self.h, int(n_rays), int(az_ptr), int(el_ptr), C.byref(o))
         self._check(rc, 'cpol_run_rays_dev')
+        return o
+
+    def run_rays_static(self, az_dev_ptr, el_dev_ptr, n_rays, outputs=None):
+        """cpol_run_rays_static: the allocation-free variant of run_rays_dev (device arrays in, every workspace from
+        the library's static per-GPU array; at most STATIC_MAX_POSITIONS ray x sub-beam x gate positions)."""
+        o = outputs if outputs is not None else CpolOutputs()
+        rc = self.lib.cpol_run_rays_static(self.h, int(n_rays), int(az_dev_ptr), int(el_dev_ptr), C.byref(o))
+        self._check(rc, 'cpol_run_rays_static')
         return o
 
     def geolocate(self, azimuth, elevation):

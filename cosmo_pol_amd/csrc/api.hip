@@ -5,9 +5,24 @@
 #include <string.h>
 #include <mutex>
 
+static int fail(cpol_ctx *ctx, int code, const char *msg);
+
+// Make sure workspace b holds at least `bytes`.  Normally a grow-only hipMalloc'ed buffer; while a call runs on
+// the static scratch (ctx->arena set) the buffer is the next 256-byte aligned piece of that array instead and
+// nothing is allocated.
 static int ensure(cpol_ctx *ctx, cpol_ctx::Buf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
+    if (ctx->arena) {
+        if (b.cap >= bytes) return CPOL_OK;
+        const size_t off = (ctx->arena_off + 255) & ~(size_t)255;
+        if (off + bytes > ctx->arena_cap)
+            return fail(ctx, CPOL_ERR_ARG, "the call needs more workspace than the static scratch array holds");
+        b.p = ctx->arena + off;
+        b.cap = bytes;
+        ctx->arena_off = off + bytes;
+        return CPOL_OK;
+    }
     if (b.cap >= bytes) return CPOL_OK;
     if (b.p) HIPCHK(ctx, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
@@ -37,7 +52,8 @@ struct StageTimer {
     cpol_ctx *ctx; int stage; hipEvent_t a = nullptr;
     StageTimer(cpol_ctx *c, int st) : ctx(c), stage(st)
     {
-        if (ctx->timing && (a = next_event(ctx))) (void)hipEventRecord(a, ctx->stream);
+        // no events (their creation allocates) while a call runs on the static scratch
+        if (ctx->timing && !ctx->arena && (a = next_event(ctx))) (void)hipEventRecord(a, ctx->stream);
     }
     ~StageTimer()
     {
@@ -114,8 +130,6 @@ extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters,
     return CPOL_OK;
 }
 
-static int fail(cpol_ctx *ctx, int code, const char *msg);
-
 extern "C" int cpol_set_batch_units(cpol_ctx *ctx, long max_units)
 {
     if (!ctx || max_units < 1) return CPOL_ERR_ARG;
@@ -131,13 +145,32 @@ static int fail(cpol_ctx *ctx, int code, const char *msg)
     return code;
 }
 
+// Workspace of cpol_run_rays_static, the entry point that must not allocate: one array per GPU the library runs
+// on, held until the process ends.  `scratch` is a host-side stand-in for the symbol, not a device address: the
+// address on each device comes from hipGetSymbolAddress (once per device, in cpol_create) and only that pointer
+// is ever handed to kernels, memsets or copies.
+#define CPOL_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char scratch[CPOL_STATIC_SCRATCH_BYTES];
+#define CPOL_MAX_DEVICES 64
+static void *g_scratch_ptr[CPOL_MAX_DEVICES];      // device address of `scratch` on each device, nullptr = not asked yet
+static std::mutex g_scratch_mutex;
+
 extern "C" int cpol_create(int device, cpol_ctx **out)
 {
     if (!out) return CPOL_ERR_ARG;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CPOL_ERR_HIP;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n || device >= CPOL_MAX_DEVICES) return CPOL_ERR_HIP;
     if (hipSetDevice(device) != hipSuccess) return CPOL_ERR_HIP;
+    {
+        // every GPU holds its own copy of the array at its own address
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void *p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return CPOL_ERR_HIP;
+            g_scratch_ptr[device] = p;
+        }
+    }
     cpol_ctx *ctx = new cpol_ctx();
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return CPOL_ERR_HIP; }
@@ -184,6 +217,20 @@ extern "C" int cpol_synchronize(cpol_ctx *ctx)
     return CPOL_OK;
 }
 
+static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build);
+
+// Build the lookup-table images as soon as the configuration and every table of its microphysics scheme are
+// known, so that the hot-path calls find them ready (and the allocation-free one can rely on that).
+static int prepare_images(cpol_ctx *ctx)
+{
+    if (!ctx->have_cfg) return CPOL_OK;
+    const int n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
+    for (int h = 0; h < n_cls; h++) if (!ctx->lut[h].present) return CPOL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ClassTable ct;
+    return build_class_table(ctx, ct, true);
+}
+
 extern "C" int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg)
 {
     if (!ctx || !cfg) return CPOL_ERR_ARG;
@@ -203,7 +250,7 @@ extern "C" int cpol_set_config(cpol_ctx *ctx, const cpol_config *cfg)
         ctx->cfg.earth_radius = sqrt((n1 * n1 + n2 * n2) / (d1 * d1 + d2 * d2));
     }
     ctx->have_cfg = true;
-    return CPOL_OK;
+    return prepare_images(ctx);
 }
 
 extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, const float *const *data,
@@ -228,8 +275,8 @@ extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, c
     if ((double)nvox * (nvp / 4) >= 2147483648.) return fail(ctx, CPOL_ERR_ARG, "model too large: nz*ny*nx*ceil(nvars/4) must stay below 2^31");
     HIPCHK(ctx, hipMalloc((void **)&ctx->dcol, nvox * nvp * sizeof(float)));
     if (nvp != nvars) HIPCHK(ctx, hipMemsetAsync(ctx->dcol, 0, nvox * nvp * sizeof(float), ctx->stream));
-    TRY(ensure(ctx, ctx->b_stage, nvox * sizeof(float)));
-    float *stage = (float *)ctx->b_stage.p;
+    TRY(ensure(ctx, ctx->w->b_stage, nvox * sizeof(float)));
+    float *stage = (float *)ctx->w->b_stage.p;
     HIPCHK(ctx, hipMemcpyAsync(stage, zlev, nvox * sizeof(float), hipMemcpyDefault, ctx->stream));
     launch_transpose_levels(ctx->stream, stage, ctx->zcol, nz, ncell, 1, 0);
     launch_coarse_levels(ctx->stream, ctx->zcol, ctx->zc8, nz, ncell);
@@ -294,7 +341,7 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
     L.psd = *psd;
     L.psd_dop = psd_doppler ? *psd_doppler : *psd;
     L.present = true;
-    return CPOL_OK;
+    return prepare_images(ctx);
 }
 
 extern "C" int cpol_set_turbulence(cpol_ctx *ctx, int enable, double beamwidth_deg, double kolmogorov_a)
@@ -381,8 +428,9 @@ static double xref_of(const LutDev &L, double nu)
 }
 
 // Class table of the configured schemes; (re)builds the lookup-table images when the column
-// layout they were built for differs from what the configuration needs.
-static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
+// layout they were built for differs from what the configuration needs.  With allow_build = false nothing is
+// allocated or built: stale or missing images are an error (the entry point that must not allocate).
+static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
 {
     memset(&ct, 0, sizeof(ct));
     ct.n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
@@ -402,6 +450,9 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct)
         const int want_dop_img = ct.n_kinds == 2 ? 1 : 0;
         const int tag = ct.ncol * 4 + (shared ? 2 : 0) + want_dop_img;
         if (L.image_ncol != tag) {
+            if (!allow_build)
+                return fail(ctx, CPOL_ERR_STATE, "the lookup-table images of this configuration have not been built yet: "
+                                                 "call cpol_set_config and cpol_upload_lut (which build them) first");
             if (L.table) { HIPCHK(ctx, hipFree(L.table)); L.table = nullptr; }
             if (L.table_dop) { HIPCHK(ctx, hipFree(L.table_dop)); L.table_dop = nullptr; }
             if (!L.xq) HIPCHK(ctx, hipMalloc((void **)&L.xq, 1024 * sizeof(float)));
@@ -482,30 +533,31 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const long nslots = nu * n_planes;
     const int nb = n_planes * ct.ne_max * ct.nt_max;
     const int nb_pol = ct.n_cls * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
-    TRY(ensure(ctx, ctx->b_key, nslots * sizeof(cpol_key_t)));
-    TRY(ensure(ctx, ctx->b_lam, nslots * sizeof(float2)));
-    TRY(ensure(ctx, ctx->b_coef, nslots * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
-    TRY(ensure(ctx, ctx->b_rank, nslots * sizeof(int)));
-    TRY(ensure(ctx, ctx->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
-    if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
-    TRY(ensure(ctx, ctx->b_cbkt, (size_t)((nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb + 1) * sizeof(int)));
-    TRY(ensure(ctx, ctx->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
-    if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->b_vr, nu * sizeof(double)));
-    if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->b_n0d, nslots * sizeof(double)));
-    int *hist = (int *)ctx->b_hist.p, *cursor = hist + CPOL_SORT_SHARDS * (nb + 1), *offs = cursor + CPOL_SORT_SHARDS * (nb + 1),
+    TRY(ensure(ctx, ctx->w->b_key, nslots * sizeof(cpol_key_t)));
+    TRY(ensure(ctx, ctx->w->b_lam, nslots * sizeof(float2)));
+    TRY(ensure(ctx, ctx->w->b_coef, nslots * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
+    TRY(ensure(ctx, ctx->w->b_rank, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
+    if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->w->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
+    TRY(ensure(ctx, ctx->w->b_cbkt, (size_t)((nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb + 1) * sizeof(int)));
+    TRY(ensure(ctx, ctx->w->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
+    if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->w->b_vr, nu * sizeof(double)));
+    if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->w->b_n0d, nslots * sizeof(double)));
+    int *hist = (int *)ctx->w->b_hist.p, *cursor = hist + CPOL_SORT_SHARDS * (nb + 1), *offs = cursor + CPOL_SORT_SHARDS * (nb + 1),
         *chunk_off = offs + (nb + 1);
     {
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
     launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
-                (cpol_key_t *)ctx->b_key.p, (int *)ctx->b_rank.p, (float2 *)ctx->b_lam.p, (double *)ctx->b_coef.p,
-                (double *)ctx->b_n0d.p, hist, (double *)ctx->b_vr.p);
-    launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->b_cbkt.p);
-    launch_scatter(ctx->stream, nu, ct.n_cls, (const cpol_key_t *)ctx->b_key.p, (const int *)ctx->b_rank.p, offs, cursor,
-                   (int *)ctx->b_sorted.p);
+                (cpol_key_t *)ctx->w->b_key.p, (int *)ctx->w->b_rank.p, (float2 *)ctx->w->b_lam.p, (double *)ctx->w->b_coef.p,
+                (double *)ctx->w->b_n0d.p, hist, (double *)ctx->w->b_vr.p);
+    launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->w->b_cbkt.p);
+    launch_scatter(ctx->stream, nu, ct.n_cls, (const cpol_key_t *)ctx->w->b_key.p, (const int *)ctx->w->b_rank.p, offs, cursor,
+                   (int *)ctx->w->b_sorted.p);
     }
-    if (ctx->timing) {
+    const bool count_work = ctx->timing && !ctx->arena;
+    if (count_work) {
         // number of valid units of this batch (offs[nb]) for the work counters
         if (ctx->valid_used == ctx->valid_cap) {
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -523,14 +575,14 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const long max_chunks = (nu * ct.n_cls + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb_pol;
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
-    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->b_cbkt.p, (int *)ctx->b_sorted.p,
-                     (const float2 *)ctx->b_lam.p, (float *)ctx->b_psd.p, ctx->timing ? ctx->work_dev : nullptr);
+    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->w->b_cbkt.p, (int *)ctx->w->b_sorted.p,
+                     (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, count_work ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
-        launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->b_cbkt.p, (const int *)ctx->b_sorted.p,
-                             (const float2 *)ctx->b_lam.p, (const double *)ctx->b_n0d.p, (float2 *)ctx->b_dop.p, (long)ct.n_cls * nu,
-                             ctx->timing ? ctx->work_dev : nullptr);
+        launch_integrate_dop(ctx->stream, ct, max_chunks, nb_pol, nb, offs, chunk_off, (const int *)ctx->w->b_cbkt.p, (const int *)ctx->w->b_sorted.p,
+                             (const float2 *)ctx->w->b_lam.p, (const double *)ctx->w->b_n0d.p, (float2 *)ctx->w->b_dop.p, (long)ct.n_cls * nu,
+                             count_work ? ctx->work_dev : nullptr);
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
@@ -539,8 +591,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     memset(&d2, 0, sizeof(d2));
     if (ctx->cfg.doppler_scheme == 2) {
         d2.vals = vals; d2.plane = plane; d2.elev = elev; d2.phi_sc = phi;
-        d2.lam = (const float2 *)ctx->b_lam.p; d2.n0d = (const double *)ctx->b_n0d.p;
-        d2.dop_out = (const float2 *)ctx->b_dop.p;
+        d2.lam = (const float2 *)ctx->w->b_lam.p; d2.n0d = (const double *)ctx->w->b_n0d.p;
+        d2.dop_out = (const float2 *)ctx->w->b_dop.p;
         d2.n_cls = ct.n_cls; d2.ne_max = ct.ne_max; d2.nt_max = ct.nt_max; d2.shared = ct.dop_shared;
         if (ct.dop_shared) {       // columns 12, 13 of the 14-column image; d = 1023 is (q, k, s) = (63, 3, 3)
             d2.slice_floats = 1024 * 14;
@@ -600,8 +652,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         launch_spectrum(ctx->stream, ct, sp, nr, nu, vals, plane, elev, mask, wsub, phi, ctx->varray_dev,
                         ctx->rawptr_dev, ctx->rawptr_dev + CPOL_MAX_CLASSES, spectrum, rvel_out, ray0);
     }
-    launch_observables(ctx->stream, op, nr, nu, (const cpol_key_t *)ctx->b_key.p, (const double *)ctx->b_coef.p,
-                       (const float *)ctx->b_psd.p, mask, wsub, (const double *)ctx->b_vr.p, obs, obs_plane, ray0,
+    launch_observables(ctx->stream, op, nr, nu, (const cpol_key_t *)ctx->w->b_key.p, (const double *)ctx->w->b_coef.p,
+                       (const float *)ctx->w->b_psd.p, mask, wsub, (const double *)ctx->w->b_vr.p, obs, obs_plane, ray0,
                        mask_out, rvel_out, d2, spectrum, ctx->n_vel);
     HIPCHK(ctx, hipGetLastError());
     return CPOL_OK;
@@ -631,26 +683,25 @@ static void geom_params(const cpol_ctx *ctx, GeomParams &gp)
 
 static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)
 {
-    TRY(ensure(ctx, ctx->b_S, nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_H, nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_E, nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_lat, nu * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_lon, nu * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_coords, nu * 2 * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_line, (size_t)nrb * CPOL_LINE_N * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_phi, (size_t)nrb * 2 * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_S, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->b_H, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->b_E, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->b_lat, nu * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_lon, nu * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_coords, nu * 2 * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->b_line, (size_t)nrb * CPOL_LINE_N * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_phi, (size_t)nrb * 2 * sizeof(double)));
     return CPOL_OK;
 }
 
-extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
-                                 cpol_outputs *out)
+// The hot path for n_rays rays.  no_alloc = false: the workspaces are the ctx's grow-only heap buffers and the
+// rays go through in batches.  no_alloc = true (cpol_run_rays_static): ctx->arena is set, every workspace is a
+// piece of the static scratch, azimuth / elevation are device arrays used in place, and nothing is allocated.
+static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                         cpol_outputs *out, bool no_alloc)
 {
-    TRY(check_ready(ctx, true, true));
-    if (n_rays == 0) return CPOL_OK;              // an empty scan is not an error
-    if (n_rays < 0 || !azimuth || !elevation || !out) return CPOL_ERR_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
     ClassTable ct;
-    TRY(build_class_table(ctx, ct));
+    TRY(build_class_table(ctx, ct, !no_alloc));
     // every variable the scheme reads must have been uploaded
     {
         bool have[CPOL_V_COUNT] = {false};
@@ -665,32 +716,39 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
     }
     const int B = ctx->n_sub, G = ctx->cfg.n_gates;
     const long RG = (long)n_rays * G;
-    TRY(ensure(ctx, ctx->b_az, n_rays * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_el, n_rays * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_status, n_rays * sizeof(int)));
-    if (!out->obs) { TRY(ensure(ctx, ctx->o_obs, (size_t)CPOL_N_OBS * RG * sizeof(float))); out->obs = (float *)ctx->o_obs.p; }
-    if (!out->rvel) { TRY(ensure(ctx, ctx->o_rvel, RG * sizeof(double))); out->rvel = (double *)ctx->o_rvel.p; }
-    if (!out->mask) { TRY(ensure(ctx, ctx->o_mask, RG * sizeof(double))); out->mask = (double *)ctx->o_mask.p; }
-    if (!out->lat) { TRY(ensure(ctx, ctx->o_lat, RG * sizeof(double))); out->lat = (double *)ctx->o_lat.p; }
-    if (!out->lon) { TRY(ensure(ctx, ctx->o_lon, RG * sizeof(double))); out->lon = (double *)ctx->o_lon.p; }
-    if (!out->dist) { TRY(ensure(ctx, ctx->o_dist, RG * sizeof(float))); out->dist = (float *)ctx->o_dist.p; }
-    if (!out->height) { TRY(ensure(ctx, ctx->o_height, RG * sizeof(float))); out->height = (float *)ctx->o_height.p; }
+    cpol_ctx::Work &w = *ctx->w;
+    if (!out->obs) { TRY(ensure(ctx, w.o_obs, (size_t)CPOL_N_OBS * RG * sizeof(float))); out->obs = (float *)w.o_obs.p; }
+    if (!out->rvel) { TRY(ensure(ctx, w.o_rvel, RG * sizeof(double))); out->rvel = (double *)w.o_rvel.p; }
+    if (!out->mask) { TRY(ensure(ctx, w.o_mask, RG * sizeof(double))); out->mask = (double *)w.o_mask.p; }
+    if (!out->lat) { TRY(ensure(ctx, w.o_lat, RG * sizeof(double))); out->lat = (double *)w.o_lat.p; }
+    if (!out->lon) { TRY(ensure(ctx, w.o_lon, RG * sizeof(double))); out->lon = (double *)w.o_lon.p; }
+    if (!out->dist) { TRY(ensure(ctx, w.o_dist, RG * sizeof(float))); out->dist = (float *)w.o_dist.p; }
+    if (!out->height) { TRY(ensure(ctx, w.o_height, RG * sizeof(float))); out->height = (float *)w.o_height.p; }
+    if (!out->ray_status) { TRY(ensure(ctx, w.b_status, n_rays * sizeof(int))); out->ray_status = (int *)w.b_status.p; }
     if (ctx->cfg.doppler_scheme == 3) {
         if (ctx->n_vel < 2) return fail(ctx, CPOL_ERR_STATE, "doppler_scheme 3: cpol_set_velocity_bins has not been called");
-        if (!out->dspectrum) { TRY(ensure(ctx, ctx->o_spec, (size_t)RG * ctx->n_vel * sizeof(double))); out->dspectrum = (double *)ctx->o_spec.p; }
+        if (!out->dspectrum) { TRY(ensure(ctx, w.o_spec, (size_t)RG * ctx->n_vel * sizeof(double))); out->dspectrum = (double *)w.o_spec.p; }
     } else out->dspectrum = nullptr;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->b_status.p, 0, n_rays * sizeof(int), ctx->stream));
+    const double *az_dev = azimuth, *el_dev = elevation;
+    if (!no_alloc) {
+        // host or device arrays: a copy of either kind puts them on the device
+        TRY(ensure(ctx, w.b_az, n_rays * sizeof(double)));
+        TRY(ensure(ctx, w.b_el, n_rays * sizeof(double)));
+        HIPCHK(ctx, hipMemcpyAsync(w.b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(w.b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, ctx->stream));
+        az_dev = (const double *)w.b_az.p; el_dev = (const double *)w.b_el.p;
+    }
+    int *status = out->ray_status;
+    HIPCHK(ctx, hipMemsetAsync(status, 0, n_rays * sizeof(int), ctx->stream));
 
     long per_ray = (long)B * G;
     int rays_per_batch = (int)(ctx->max_batch_units / per_ray);
     if (rays_per_batch < 1) rays_per_batch = 1;
-    if (rays_per_batch > n_rays) rays_per_batch = n_rays;
+    if (rays_per_batch > n_rays || no_alloc) rays_per_batch = n_rays;
     long nu_max = (long)rays_per_batch * per_ray;
     TRY(ensure_geom(ctx, (long)rays_per_batch * B, nu_max));
-    TRY(ensure(ctx, ctx->b_vals, (size_t)CPOL_V_COUNT * nu_max * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_mask, nu_max));
+    TRY(ensure(ctx, w.b_vals, (size_t)CPOL_V_COUNT * nu_max * sizeof(float)));
+    TRY(ensure(ctx, w.b_mask, nu_max));
     GeomParams gp;
     geom_params(ctx, gp);
     ModelView mv;
@@ -701,29 +759,60 @@ extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimut
         long nu = (long)nr * per_ray;
         {
             StageTimer t_(ctx, CPOL_ST_GEOM);
-            launch_geom(ctx->stream, gp, nr, (const double *)ctx->b_az.p + r0, (const double *)ctx->b_el.p + r0,
-                        ctx->quad_dev, (double *)ctx->b_line.p, (float *)ctx->b_S.p, (float *)ctx->b_H.p,
-                        (float *)ctx->b_E.p, (double *)ctx->b_lat.p, (double *)ctx->b_lon.p, (float *)ctx->b_coords.p,
-                        (double *)ctx->b_phi.p, mv, (int *)ctx->b_status.p + r0);
-            launch_gather_central(ctx->stream, nr, B, G, (const float *)ctx->b_S.p, (const float *)ctx->b_H.p,
-                                  (const double *)ctx->b_lat.p, (const double *)ctx->b_lon.p, out->dist,
+            launch_geom(ctx->stream, gp, nr, az_dev + r0, el_dev + r0,
+                        ctx->quad_dev, (double *)w.b_line.p, (float *)w.b_S.p, (float *)w.b_H.p,
+                        (float *)w.b_E.p, (double *)w.b_lat.p, (double *)w.b_lon.p, (float *)w.b_coords.p,
+                        (double *)w.b_phi.p, mv, status + r0);
+            launch_gather_central(ctx->stream, nr, B, G, (const float *)w.b_S.p, (const float *)w.b_H.p,
+                                  (const double *)w.b_lat.p, (const double *)w.b_lon.p, out->dist,
                                   out->height, out->lat, out->lon, r0);
         }
         {
             StageTimer t_(ctx, CPOL_ST_INTERP);
-            launch_interp(ctx->stream, mv, nu, (const float *)ctx->b_coords.p, (const float *)ctx->b_H.p,
-                          (float *)ctx->b_vals.p, nu_max, (signed char *)ctx->b_mask.p, nullptr);
+            launch_interp(ctx->stream, mv, nu, (const float *)w.b_coords.p, (const float *)w.b_H.p,
+                          (float *)w.b_vals.p, nu_max, (signed char *)w.b_mask.p, nullptr);
         }
-        TRY(run_physics(ctx, ct, nr, B, G, (const float *)ctx->b_vals.p, nu_max, (const float *)ctx->b_E.p,
-                        (const signed char *)ctx->b_mask.p, wsub, (const double *)ctx->b_phi.p,
+        TRY(run_physics(ctx, ct, nr, B, G, (const float *)w.b_vals.p, nu_max, (const float *)w.b_E.p,
+                        (const signed char *)w.b_mask.p, wsub, (const double *)w.b_phi.p,
                         out->obs, RG, r0, out->mask, out->rvel, out->dspectrum));
     }
     HIPCHK(ctx, hipGetLastError());
     if (!ctx->cfg.doppler_scheme) out->rvel = nullptr;
-    if (out->ray_status) {
-        HIPCHK(ctx, hipMemcpyAsync(out->ray_status, ctx->b_status.p, n_rays * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    } else out->ray_status = (int *)ctx->b_status.p;
     return CPOL_OK;
+}
+
+extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                                 cpol_outputs *out)
+{
+    TRY(check_ready(ctx, true, true));
+    if (n_rays == 0) return CPOL_OK;              // an empty scan is not an error
+    if (n_rays < 0 || !azimuth || !elevation || !out) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return run_rays_impl(ctx, n_rays, azimuth, elevation, out, false);
+}
+
+extern "C" int cpol_run_rays_static(cpol_ctx *ctx, int n_rays, const double *azimuth_dev, const double *elevation_dev,
+                                    cpol_outputs *out)
+{
+    TRY(check_ready(ctx, true, true));
+    if (n_rays == 0) return CPOL_OK;
+    if (n_rays < 0 || !azimuth_dev || !elevation_dev || !out) return CPOL_ERR_ARG;
+    if (ctx->cfg.doppler_scheme == 3)
+        return fail(ctx, CPOL_ERR_ARG, "cpol_run_rays_static does not serve doppler_scheme 3 (its tables are built on first use)");
+    const long positions = (long)n_rays * ctx->n_sub * ctx->cfg.n_gates;
+    if (positions > CPOL_STATIC_MAX_POSITIONS)
+        return fail(ctx, CPOL_ERR_ARG, "cpol_run_rays_static: n_rays x sub-beams x gates exceeds CPOL_STATIC_MAX_POSITIONS");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *base = g_scratch_ptr[ctx->device];      // set by cpol_create on this device
+    if (!base) return fail(ctx, CPOL_ERR_STATE, "the static scratch array has no address on this device");
+    // every workspace of this call is a piece of the static array; the heap buffers are left as they are
+    ctx->arena_work = cpol_ctx::Work();
+    ctx->w = &ctx->arena_work;
+    ctx->arena = (char *)base; ctx->arena_cap = CPOL_STATIC_SCRATCH_BYTES; ctx->arena_off = 0;
+    const int rc = run_rays_impl(ctx, n_rays, azimuth_dev, elevation_dev, out, true);
+    ctx->arena = nullptr; ctx->arena_cap = 0;
+    ctx->w = &ctx->heap;
+    return rc;
 }
 
 extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
@@ -760,30 +849,30 @@ extern "C" int cpol_geolocate(cpol_ctx *ctx, int n_rays, const double *azimuth, 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int B = ctx->n_sub, G = ctx->cfg.n_gates;
     const long nu = (long)n_rays * B * G;
-    TRY(ensure(ctx, ctx->b_az, n_rays * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_el, n_rays * sizeof(double)));
-    TRY(ensure(ctx, ctx->b_status, n_rays * sizeof(int)));
+    TRY(ensure(ctx, ctx->w->b_az, n_rays * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_el, n_rays * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_status, n_rays * sizeof(int)));
     TRY(ensure_geom(ctx, (long)n_rays * B, nu));
     hipStream_t s = ctx->stream;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, s));
-    HIPCHK(ctx, hipMemsetAsync(ctx->b_status.p, 0, n_rays * sizeof(int), s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->b_az.p, azimuth, n_rays * sizeof(double), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->b_el.p, elevation, n_rays * sizeof(double), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->w->b_status.p, 0, n_rays * sizeof(int), s));
     GeomParams gp;
     geom_params(ctx, gp);
     ModelView mv;
     build_model_view(ctx, mv);
-    launch_geom(s, gp, n_rays, (const double *)ctx->b_az.p, (const double *)ctx->b_el.p, ctx->quad_dev,
-                (double *)ctx->b_line.p, (float *)ctx->b_S.p, (float *)ctx->b_H.p, (float *)ctx->b_E.p,
-                (double *)ctx->b_lat.p, (double *)ctx->b_lon.p, (float *)ctx->b_coords.p, (double *)ctx->b_phi.p, mv,
-                (int *)ctx->b_status.p);
+    launch_geom(s, gp, n_rays, (const double *)ctx->w->b_az.p, (const double *)ctx->w->b_el.p, ctx->quad_dev,
+                (double *)ctx->w->b_line.p, (float *)ctx->w->b_S.p, (float *)ctx->w->b_H.p, (float *)ctx->w->b_E.p,
+                (double *)ctx->w->b_lat.p, (double *)ctx->w->b_lon.p, (float *)ctx->w->b_coords.p, (double *)ctx->w->b_phi.p, mv,
+                (int *)ctx->w->b_status.p);
     HIPCHK(ctx, hipGetLastError());
-    if (dist) HIPCHK(ctx, hipMemcpyAsync(dist, ctx->b_S.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (height) HIPCHK(ctx, hipMemcpyAsync(height, ctx->b_H.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (elev) HIPCHK(ctx, hipMemcpyAsync(elev, ctx->b_E.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (lat) HIPCHK(ctx, hipMemcpyAsync(lat, ctx->b_lat.p, nu * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (lon) HIPCHK(ctx, hipMemcpyAsync(lon, ctx->b_lon.p, nu * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (coords_rot) HIPCHK(ctx, hipMemcpyAsync(coords_rot, ctx->b_coords.p, nu * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (ray_status) HIPCHK(ctx, hipMemcpyAsync(ray_status, ctx->b_status.p, n_rays * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (dist) HIPCHK(ctx, hipMemcpyAsync(dist, ctx->w->b_S.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (height) HIPCHK(ctx, hipMemcpyAsync(height, ctx->w->b_H.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (elev) HIPCHK(ctx, hipMemcpyAsync(elev, ctx->w->b_E.p, nu * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (lat) HIPCHK(ctx, hipMemcpyAsync(lat, ctx->w->b_lat.p, nu * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (lon) HIPCHK(ctx, hipMemcpyAsync(lon, ctx->w->b_lon.p, nu * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (coords_rot) HIPCHK(ctx, hipMemcpyAsync(coords_rot, ctx->w->b_coords.p, nu * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (ray_status) HIPCHK(ctx, hipMemcpyAsync(ray_status, ctx->w->b_status.p, n_rays * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return CPOL_OK;
 }
@@ -794,16 +883,16 @@ extern "C" int cpol_interp_points(cpol_ctx *ctx, int n, const float *coords_rot,
     if (!ctx->have_model) return fail(ctx, CPOL_ERR_STATE, "no model uploaded");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    TRY(ensure(ctx, ctx->t_a, (size_t)n * 2 * sizeof(float)));
-    TRY(ensure(ctx, ctx->t_b, (size_t)n * sizeof(float)));
-    TRY(ensure(ctx, ctx->t_c, (size_t)n * ctx->nv * sizeof(float)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->t_a.p, coords_rot, (size_t)n * 2 * sizeof(float), hipMemcpyDefault, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->t_b.p, heights, (size_t)n * sizeof(float), hipMemcpyDefault, s));
+    TRY(ensure(ctx, ctx->w->t_a, (size_t)n * 2 * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->t_b, (size_t)n * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->t_c, (size_t)n * ctx->nv * sizeof(float)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->t_a.p, coords_rot, (size_t)n * 2 * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->t_b.p, heights, (size_t)n * sizeof(float), hipMemcpyDefault, s));
     ModelView mv;
     build_model_view(ctx, mv);
-    launch_interp(s, mv, n, (const float *)ctx->t_a.p, (const float *)ctx->t_b.p, nullptr, 0, nullptr, (float *)ctx->t_c.p);
+    launch_interp(s, mv, n, (const float *)ctx->w->t_a.p, (const float *)ctx->w->t_b.p, nullptr, 0, nullptr, (float *)ctx->w->t_c.p);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->t_c.p, (size_t)n * ctx->nv * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->w->t_c.p, (size_t)n * ctx->nv * sizeof(float), hipMemcpyDefault, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return CPOL_OK;
 }
@@ -818,43 +907,43 @@ extern "C" int cpol_observables_from_beams(cpol_ctx *ctx, int n_sub, int n_gates
     if (ctx->cfg.doppler_scheme && !az_sub) return fail(ctx, CPOL_ERR_ARG, "az_sub is required with a Doppler scheme");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ClassTable ct;
-    TRY(build_class_table(ctx, ct));
+    TRY(build_class_table(ctx, ct, true));
     hipStream_t s = ctx->stream;
     const long nu = (long)n_sub * n_gates;
-    TRY(ensure(ctx, ctx->b_vals, (size_t)CPOL_V_COUNT * nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_E, nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->b_mask, nu));
-    TRY(ensure(ctx, ctx->t_a, n_sub * sizeof(double)));
-    TRY(ensure(ctx, ctx->t_b, n_sub * sizeof(double)));
-    TRY(ensure(ctx, ctx->t_c, (size_t)CPOL_N_OBS * n_gates * sizeof(float)));
-    TRY(ensure(ctx, ctx->t_d, n_gates * sizeof(double)));
-    TRY(ensure(ctx, ctx->t_e, n_gates * sizeof(double)));
-    if (ctx->cfg.doppler_scheme == 3) TRY(ensure(ctx, ctx->o_spec, (size_t)n_gates * (ctx->n_vel > 0 ? ctx->n_vel : 1) * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->b_vals, (size_t)CPOL_V_COUNT * nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->b_E, nu * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->b_mask, nu));
+    TRY(ensure(ctx, ctx->w->t_a, n_sub * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->t_b, n_sub * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->t_c, (size_t)CPOL_N_OBS * n_gates * sizeof(float)));
+    TRY(ensure(ctx, ctx->w->t_d, n_gates * sizeof(double)));
+    TRY(ensure(ctx, ctx->w->t_e, n_gates * sizeof(double)));
+    if (ctx->cfg.doppler_scheme == 3) TRY(ensure(ctx, ctx->w->o_spec, (size_t)n_gates * (ctx->n_vel > 0 ? ctx->n_vel : 1) * sizeof(double)));
     std::vector<signed char> m8(nu);
     for (long i = 0; i < nu; i++) m8[i] = (signed char)(mask[i] > 0 ? 1 : (mask[i] < 0 ? -1 : 0));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_vals.p, values, (size_t)CPOL_V_COUNT * nu * sizeof(float), hipMemcpyDefault, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_E.p, elev, nu * sizeof(float), hipMemcpyDefault, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->b_mask.p, m8.data(), nu, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->t_a.p, weight, n_sub * sizeof(double), hipMemcpyDefault, s));
-    TRY(ensure(ctx, ctx->b_phi, (size_t)n_sub * 2 * sizeof(double)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->b_vals.p, values, (size_t)CPOL_V_COUNT * nu * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->b_E.p, elev, nu * sizeof(float), hipMemcpyDefault, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->b_mask.p, m8.data(), nu, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->w->t_a.p, weight, n_sub * sizeof(double), hipMemcpyDefault, s));
+    TRY(ensure(ctx, ctx->w->b_phi, (size_t)n_sub * 2 * sizeof(double)));
     if (az_sub) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->t_b.p, az_sub, n_sub * sizeof(double), hipMemcpyDefault, s));
-        launch_sincos_deg(s, n_sub, (const double *)ctx->t_b.p, (double *)ctx->b_phi.p);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->w->t_b.p, az_sub, n_sub * sizeof(double), hipMemcpyDefault, s));
+        launch_sincos_deg(s, n_sub, (const double *)ctx->w->t_b.p, (double *)ctx->w->b_phi.p);
     }
     HIPCHK(ctx, hipStreamSynchronize(s));      // m8 is a local buffer
     int save_sens = ctx->cfg.sensitivity_mode;
     ctx->cfg.sensitivity_mode = 0;             // get_radar_observables itself applies no cut
-    int rc = run_physics(ctx, ct, 1, n_sub, n_gates, (const float *)ctx->b_vals.p, nu, (const float *)ctx->b_E.p,
-                         (const signed char *)ctx->b_mask.p, (const double *)ctx->t_a.p, (const double *)ctx->b_phi.p,
-                         (float *)ctx->t_c.p, n_gates, 0, (double *)ctx->t_d.p, (double *)ctx->t_e.p,
-                         ctx->cfg.doppler_scheme == 3 ? (double *)ctx->o_spec.p : nullptr);
+    int rc = run_physics(ctx, ct, 1, n_sub, n_gates, (const float *)ctx->w->b_vals.p, nu, (const float *)ctx->w->b_E.p,
+                         (const signed char *)ctx->w->b_mask.p, (const double *)ctx->w->t_a.p, (const double *)ctx->w->b_phi.p,
+                         (float *)ctx->w->t_c.p, n_gates, 0, (double *)ctx->w->t_d.p, (double *)ctx->w->t_e.p,
+                         ctx->cfg.doppler_scheme == 3 ? (double *)ctx->w->o_spec.p : nullptr);
     ctx->cfg.sensitivity_mode = save_sens;
     TRY(rc);
-    if (obs) HIPCHK(ctx, hipMemcpyAsync(obs, ctx->t_c.p, (size_t)CPOL_N_OBS * n_gates * sizeof(float), hipMemcpyDefault, s));
-    if (mask_out) HIPCHK(ctx, hipMemcpyAsync(mask_out, ctx->t_d.p, n_gates * sizeof(double), hipMemcpyDefault, s));
-    if (rvel && ctx->cfg.doppler_scheme) HIPCHK(ctx, hipMemcpyAsync(rvel, ctx->t_e.p, n_gates * sizeof(double), hipMemcpyDefault, s));
+    if (obs) HIPCHK(ctx, hipMemcpyAsync(obs, ctx->w->t_c.p, (size_t)CPOL_N_OBS * n_gates * sizeof(float), hipMemcpyDefault, s));
+    if (mask_out) HIPCHK(ctx, hipMemcpyAsync(mask_out, ctx->w->t_d.p, n_gates * sizeof(double), hipMemcpyDefault, s));
+    if (rvel && ctx->cfg.doppler_scheme) HIPCHK(ctx, hipMemcpyAsync(rvel, ctx->w->t_e.p, n_gates * sizeof(double), hipMemcpyDefault, s));
     if (dspectrum && ctx->cfg.doppler_scheme == 3)
-        HIPCHK(ctx, hipMemcpyAsync(dspectrum, ctx->o_spec.p, (size_t)n_gates * ctx->n_vel * sizeof(double), hipMemcpyDefault, s));
+        HIPCHK(ctx, hipMemcpyAsync(dspectrum, ctx->w->o_spec.p, (size_t)n_gates * ctx->n_vel * sizeof(double), hipMemcpyDefault, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     return CPOL_OK;
 }
@@ -905,8 +994,8 @@ extern "C" float *get_refl(float *refl, int len, float *Da, int len_D_bins_x, in
     const int nb = len_D_bins_x, nd = o5;
     size_t fb = sizeof(float);
     size_t total = (size_t)len + 2 * (size_t)nb * 3 + 2 * (size_t)nd * 3 + 18;
-    if (ensure(ctx, ctx->t_a, total * fb) != CPOL_OK) return nullptr;
-    float *d_refl = (float *)ctx->t_a.p, *d_Da = d_refl + len, *d_Db = d_Da + nb * 3, *d_D = d_Db + nb * 3,
+    if (ensure(ctx, ctx->w->t_a, total * fb) != CPOL_OK) return nullptr;
+    float *d_refl = (float *)ctx->w->t_a.p, *d_Da = d_refl + len, *d_Db = d_Da + nb * 3, *d_D = d_Db + nb * 3,
           *d_rcs = d_D + nd * 3, *d_par = d_rcs + nd * 3;
     keep(hipMemsetAsync(d_refl, 0, len * fb, s));
     keep(hipMemcpyAsync(d_Da, Da, nb * 3 * fb, hipMemcpyDefault, s));

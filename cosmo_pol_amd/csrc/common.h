@@ -127,12 +127,20 @@ struct cpol_ctx {
     double *refr_keys = nullptr;
     float *refr_tab = nullptr;            // [3][n_refr][n_gates]: S, H, E
     int refr_gates = 0;
-    // grow-only device workspaces
+    // Device workspaces of the kernels.  `heap` holds grow-only hipMalloc'ed buffers; `arena_work` is the same set
+    // of buffers carved out of the per-device static scratch array for the entry point that must not allocate
+    // (cpol_run_rays_static).  `w` points at the set in use.
     struct Buf { void *p = nullptr; size_t cap = 0; };
-    std::vector<Buf *> bufs;
-    Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-        b_sorted, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
-        o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
+    struct Work {
+        Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
+            b_sorted, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+            o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
+    };
+    Work heap, arena_work;
+    Work *w = &heap;
+    std::vector<Buf *> bufs;              // heap buffers to free
+    char  *arena = nullptr;               // non-null while a call carves its buffers from the static scratch
+    size_t arena_cap = 0, arena_off = 0;
     size_t max_batch_units = (size_t)32 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
     unsigned long long *work_dev = nullptr;       // 2 x 64 partial counts of unit x 16-diameter steps evaluated by k_integrate / k_integrate_dop (timing only)

@@ -206,6 +206,22 @@ int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double
 int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
                       cpol_outputs *dev_out);
 
+/* The same hot path for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same computation and same outputs as
+ * cpol_run_rays_dev, bit for bit, but the call allocates nothing: every workspace is a piece of one array of
+ * 64 MiB that the library keeps in the device memory of each GPU it runs on until the process ends.  For that:
+ *   - n_rays x sub-beams x n_gates must not exceed CPOL_STATIC_MAX_POSITIONS (CPOL_ERR_ARG otherwise);
+ *   - azimuth_dev / elevation_dev are DEVICE arrays [n_rays] and are read in place;
+ *   - cpol_set_config, cpol_upload_lut, cpol_upload_model and cpol_set_quadrature (which allocate and build the
+ *     table images) must have been called before; doppler_scheme 3 is not served (CPOL_ERR_ARG);
+ *   - members of dev_out that are NULL on entry are served from the same array and stay valid until the next
+ *     call of this entry point on that GPU; stage timing is not recorded for these calls.
+ * All calls on one GPU, from any ctx, share that GPU's array: calls that overlap on one GPU race, so run them one
+ * after the other (same stream, or synchronise in between). */
+#define CPOL_STATIC_MAX_POSITIONS 65536
+int cpol_run_rays_static(cpol_ctx *ctx, int n_rays, const double *azimuth_dev, const double *elevation_dev,
+                         cpol_outputs *dev_out);
+
 /* ---- stage-level entry points (unit parity against the reference functions) ---------- */
 /* refraction/atm_refraction.py:110-123 (ref_4_3), pyproj Geod.fwd at
  * interpolation/interpolation.py:316-325 and the rotated-pole transform of :355 for every
