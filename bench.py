@@ -6,22 +6,26 @@ Workload (BASELINE.json configs[3], "CH_PPI_lema"): one C-band PPI volume of 20 
 microphysics (4 hydrometeor classes), 3 x 3 Gauss-Hermite antenna quadrature (9 sub-beams per
 gate), attenuation correction on, Doppler scheme 2 (RCS-weighted fall speed; `--doppler 1` selects the
 closed-form scheme the reference's CH_PPI_lema.yml names).  Synthetic model state and synthetic
-lookup tables (cosmo_pol_amd/synthetic.py).  One step = one whole volume: geolocation ->
+lookup tables (tests/synthetic.py).  One step = one whole volume: geolocation ->
 trilinear interpolation -> PSD set-up / bucket sort -> PSD integration -> per-ray scans, all
-inputs and outputs resident in HBM.
+inputs and outputs resident in HBM.  `--config C1|C2|C3|C5` runs the other reference configurations.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run with one rank per GPU.  Scaling is weak: every rank
-simulates one volume (one radar of a network / one model time step) on its own replica of the
-model state and tables, so there is no data-path collective; value = all ranks' gates / time.
-`--scaling strong` instead shards the rays of ONE volume block-cyclically by azimuth over the
-ranks and gathers the output volume on rank 0 with one RCCL gather.
+N > 1: one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / WORLD_SIZE in the environment)
+the script is one rank; started plainly with --gpus N > 1 it launches the N ranks itself, as children, before
+anything touches a GPU.  The rays of ONE volume are sharded block-cyclically by azimuth over the ranks, model and
+tables replicated, and every step ends with one gather of all output fields (observables, radial velocity,
+mask, geometry) from device memory to rank 0 - the split of the reference's pool.map over rays
+(radar_operator.py:253-256).  The gather of one volume runs beside the kernels of the next (two output
+buffers).  `--scaling weak` instead lets every rank simulate a whole volume of its own (one radar of a
+network per GPU, no collective).
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,30 +41,51 @@ N_D = 1024
 FLOP_PER_UNIT = 27 * N_D          # 12 components x (mul + add) + 3 for N(D), per diameter bin
 FLOP_PER_UNIT_DOP2 = 6 * N_D      # Doppler scheme 2: two more columns (N rcs, N v rcs), mul + add + weight each
 
+# The reference's five option files as workloads (sizes as the survey of the reference restates them); C4 is the
+# headline.  kind: scan type; rays: (n_sweeps, rays per sweep).
+WORKLOADS = {
+    'C1': dict(name='test_strat PPI', kind='ppi', mp=1, gh=1, dop=1, freq=5.6, rng=50000, res=75, bw=1.45,
+               elevations=[1.0], az_step=1.45, coords=[46.04079, 8.83321, 2050]),
+    'C2': dict(name='MXPOL_RHI', kind='rhi', mp=1, gh=3, dop=1, freq=9.41, rng=50000, res=75, bw=1.45,
+               azimuths=[47.], el_step=1.45, coords=[46.04079, 8.83321, 2050]),
+    'C3': dict(name='MXPOL_RHI_new_scheme', kind='rhi', mp=2, gh=3, dop=1, freq=9.41, rng=50000, res=75, bw=1.45,
+               azimuths=[140.], el_step=1.45, coords=[46.04079, 8.83321, 2050]),
+    'C4': dict(name='CH_PPI_lema volume', kind='ppi', mp=2, gh=3, dop=2, freq=5.6, rng=250000, res=500, bw=1.0,
+               elevations=ELEVATIONS, az_step=1.0, coords=[46.04079, 8.83321, 2050]),
+    'C5': dict(name='MXPOL_RHI_PAYERNE_DOPPLER', kind='rhi', mp=1, gh=3, dop=3, freq=9.41, rng=11000, res=75, bw=1.45,
+               azimuths=[90.], el_step=1.45, coords=[46.04079, 8.83321, 2050], pri=700, fft=256),
+}
 
-def workload_config(small=False, doppler=2, microphysics=2, n_gh=3):
+
+def workload_config(small=False, doppler=2, microphysics=2, n_gh=3, config='C4', turbulence=0):
     from cosmo_pol_amd import cfg
+    w = WORKLOADS[config]
     # Monte Lema's position; the altitude is 80 m above the synthetic terrain at that grid cell (a radar below
     # the terrain would see NaN air density at its first gate, which the reference turns into NaN RVEL for
     # the whole ray, doppler_sz.py:231)
-    conf = {'radar': {'coords': [46.04079, 8.83321, 2050], 'type': 'ground', 'frequency': 5.6,
-                      'range': 250000, 'radial_resolution': 500, 'PRI': 700, 'FFT_length': 128,
-                      'sensitivity': [-15, 10000], '3dB_beamwidth': 1.},
+    conf = {'radar': {'coords': list(w['coords']), 'type': 'ground', 'frequency': w['freq'],
+                      'range': w['rng'], 'radial_resolution': w['res'], 'PRI': w.get('pri', 700),
+                      'FFT_length': w.get('fft', 128), 'sensitivity': [-15, 10000], '3dB_beamwidth': w['bw']},
             'integration': {'scheme': 1, 'nh_GH': n_gh, 'nv_GH': n_gh, 'weight_threshold': 1.},
-            'refraction': {'scheme': 1}, 'attenuation': {'correction': 1}, 'doppler': {'scheme': doppler},
+            'refraction': {'scheme': 1}, 'attenuation': {'correction': 1},
+            'doppler': {'scheme': doppler, 'turbulence_correction': int(bool(turbulence))},
             'microphysics': {'scheme': microphysics}}
     if small:
-        conf['radar']['range'] = 50000
+        conf['radar']['range'] = min(50000, w['rng'])
     cfg.set_config(conf)
     return cfg.CONFIG
 
 
-def volume_rays(small=False):
-    az = np.arange(0., 360., 1.0 if not small else 10.0)
-    els = ELEVATIONS if not small else ELEVATIONS[:4]
-    azs = np.tile(az, len(els))
-    elv = np.repeat(np.array(els, dtype=np.float64), len(az))
-    return azs, elv
+def volume_rays(small=False, config='C4'):
+    """(azimuths, elevations, n_sweeps, rays_per_sweep) of the scan, ray index = sweep * rays_per_sweep + i."""
+    w = WORKLOADS[config]
+    if w['kind'] == 'ppi':
+        az = np.arange(0., 360., w['az_step'] if not small else 10.0)
+        els = w['elevations'] if not small else w['elevations'][:4]
+        return np.tile(az, len(els)), np.repeat(np.array(els, dtype=np.float64), len(az)), len(els), len(az)
+    el = np.arange(0., 90. + w['el_step'], w['el_step'] if not small else 10.0)       # radar_operator.py:294-298
+    azs = w['azimuths']
+    return np.repeat(np.array(azs, dtype=np.float64), len(el)), np.tile(el, len(azs)), len(azs), len(el)
 
 
 # ----------------------------------------------------------------------------------------
@@ -76,19 +101,43 @@ def _cpu_ray(args):
     conf, dic, luts = _CPU['conf'], _CPU['dic'], _CPU['luts']
     with np.errstate(all='ignore'):
         beams = O.get_profiles_GH(dic, az, el, conf)
-        O.get_doppler_velocity(beams, luts, conf)
+        O.get_doppler_velocity(beams, luts, conf, **_CPU['dop_kw'])
         out = O.get_radar_observables(beams, luts, conf)
     return float(np.nansum(out.values['ZH']))
 
 
-def cpu_baseline(conf, model, tabs, azs, elv, n_rays, cores):
+def host_cpu_share():
+    """(worker count, logical CPUs this process may run on, CPU model).  The workers are the CPUs the process is
+    allowed on, capped by the job's CPU share where the environment states one (MAX_JOBS / OMP_NUM_THREADS)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    share = allowed
+    for k in ('MAX_JOBS', 'OMP_NUM_THREADS'):
+        v = os.environ.get(k, '')
+        if v.isdigit() and int(v) > 0:
+            share = min(share, int(v))
+            break
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return share, allowed, model
+
+
+def cpu_baseline(conf, model, tabs, azs, elv, n_rays, cores, allowed, cpu_model):
     import multiprocessing as mp
     from oracle import cosmo_oracle as O
-    os.environ.setdefault('OMP_NUM_THREADS', '1')
+    os.environ['OMP_NUM_THREADS'] = '1'           # one thread per pool worker
     attrs = {'z-levels': model['zlev'], 'proj_info': model['proj_info'], 'resolution': model['resolution']}
     _CPU['conf'] = conf
     _CPU['dic'] = {n: O.ModelVar(a, attrs) for n, a in model['fields'].items()}
     _CPU['luts'] = {h: O.Lut(*t) for h, t in tabs.items()}
+    _CPU['dop_kw'] = {'get_refl': O.get_refl_c} if conf['doppler']['scheme'] in (3, 4) else {}
+    n_rays = min(n_rays, len(azs))
     idx = np.linspace(0, len(azs) - 1, n_rays).astype(int)
     tasks = [(float(azs[i]), float(elv[i])) for i in idx]
     ctx = mp.get_context('fork')
@@ -99,167 +148,375 @@ def cpu_baseline(conf, model, tabs, azs, elv, n_rays, cores):
         dt = time.perf_counter() - t0
     n_gates = len(O.radar_ranges(conf))
     return {'value': n_rays * n_gates / dt, 'unit': 'gates/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d of the volume\'s %d rays (every %dth), %d gates each, whole path '
+            'cpu_model': cpu_model, 'host_logical_cpus': allowed,
+            'sample': '%d of the scan\'s %d rays (every %dth), %d gates each, whole path '
                       '(profiles_GH + doppler + observables), fork pool of %d workers, %.1f s wall'
                       % (n_rays, len(azs), max(1, len(azs) // n_rays), n_gates, cores, dt)}
 
 
-def main():
+# ----------------------------------------------------------------------------------------
+# the engine under test, and a CPU stand-in for it that lets the multi-rank structure (launch, sharding, gather,
+# JSON line) be rehearsed without GPUs
+# ----------------------------------------------------------------------------------------
+class GpuRunner(object):
+    def __init__(self, conf, model, tabs, local_rank, batch_units):
+        import torch
+        from cosmo_pol_amd import engine
+        from cosmo_pol_amd.lut import Lookup_table
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.dev = torch.device('cuda', local_rank)
+        self.eng = engine.Engine(conf, device=local_rank)
+        self.eng.upload_luts({h: Lookup_table.from_arrays(*t) for h, t in tabs.items()})
+        self.eng.upload_model(model['fields'], model['zlev'], model['proj_info'], model['resolution'])
+        self.eng.set_gauss_hermite()
+        self.ctx = self.eng.ctx
+        if batch_units:
+            self.ctx.set_batch_units(batch_units)
+        self.n_gates, self.n_sub, self.n_vel = self.eng.n_gates, self.ctx.n_sub, self.ctx.n_vel
+        self.doppler = self.ctx.doppler
+
+    def outputs(self, R, pinned_host=False):
+        torch, G = self.torch, self.n_gates
+        kw = dict(device='cpu', pin_memory=True) if pinned_host else dict(device=self.dev)
+        from cosmo_pol_amd import _lib
+        t = {'obs': torch.empty((_lib.N_OBS, R, G), dtype=torch.float32, **kw)}
+        for k in ('rvel', 'mask', 'lat', 'lon'):
+            t[k] = torch.empty((R, G), dtype=torch.float64, **kw)
+        for k in ('dist', 'height'):
+            t[k] = torch.empty((R, G), dtype=torch.float32, **kw)
+        t['ray_status'] = torch.zeros((R,), dtype=torch.int32, **kw)
+        if self.doppler == 3:
+            t['dspectrum'] = torch.empty((R, G, self.n_vel), dtype=torch.float64, **kw)
+        return t
+
+    def struct(self, t):
+        from cosmo_pol_amd import _lib
+        P = lambda x, typ: ctypes.cast(x.data_ptr(), typ)
+        return _lib.CpolOutputs(P(t['obs'], _lib.c_float_p), P(t['rvel'], _lib.c_double_p), P(t['mask'], _lib.c_double_p),
+                                P(t['lat'], _lib.c_double_p), P(t['lon'], _lib.c_double_p), P(t['dist'], _lib.c_float_p),
+                                P(t['height'], _lib.c_float_p), P(t['ray_status'], _lib.c_int_p),
+                                P(t['dspectrum'], _lib.c_double_p) if 'dspectrum' in t else None)
+
+    def angles(self, az, el):
+        return (self.torch.tensor(az, dtype=self.torch.float64, device=self.dev),
+                self.torch.tensor(el, dtype=self.torch.float64, device=self.dev))
+
+    def run(self, az_t, el_t, out_struct):
+        """Queue one pass over the rays on the library's stream (device outputs)."""
+        self.ctx.run_rays_dev(az_t.data_ptr(), el_t.data_ptr(), az_t.numel(), out_struct)
+
+    def run_host(self, az_np, el_np, out_struct):
+        """One pass with the outputs delivered to host memory (returns when they are there)."""
+        rc = self.ctx.lib.cpol_run_rays(self.ctx.h, len(az_np), az_np.ctypes.data, el_np.ctypes.data, ctypes.byref(out_struct))
+        self.ctx._check(rc, 'cpol_run_rays')
+
+    def sync(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize()
+
+
+class StubRunner(object):
+    """CPU stand-in: every output is a fixed function of (azimuth, elevation, gate).  Results are NOT measurements."""
+    n_sub, n_vel, doppler = 9, 0, 2
+
+    def __init__(self, conf):
+        import torch
+        self.torch = torch
+        self.dev = torch.device('cpu')
+        r = conf['radar']
+        self.n_gates = len(np.arange(r['radial_resolution'] / 2, r['range'], r['radial_resolution']))
+
+    def outputs(self, R, pinned_host=False):
+        torch, G = self.torch, self.n_gates
+        t = {'obs': torch.empty((9, R, G), dtype=torch.float32)}
+        for k in ('rvel', 'mask', 'lat', 'lon'):
+            t[k] = torch.empty((R, G), dtype=torch.float64)
+        for k in ('dist', 'height'):
+            t[k] = torch.empty((R, G), dtype=torch.float32)
+        t['ray_status'] = torch.zeros((R,), dtype=torch.int32)
+        return t
+
+    def struct(self, t):
+        return t
+
+    def angles(self, az, el):
+        return self.torch.tensor(az, dtype=self.torch.float64), self.torch.tensor(el, dtype=self.torch.float64)
+
+    def run(self, az_t, el_t, t):
+        g = self.torch.arange(self.n_gates, dtype=self.torch.float64)[None, :]
+        base = az_t[:, None] * 10. + el_t[:, None] * 1000. + g
+        for i in range(9):
+            t['obs'][i] = (base + 0.5 * i).float()
+        t['rvel'].copy_(base * 2.)
+        t['mask'].zero_()
+        t['lat'].copy_(base + 0.25)
+        t['lon'].copy_(base + 0.75)
+        t['dist'].copy_((g + 0 * base).float())
+        t['height'].copy_((base * 3).float())
+
+    def sync(self):
+        pass
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script as children through torch.distributed.run and return their exit status.  The
+    parent never touches a GPU, so nothing that has initialised one is ever replaced or forked."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
-    ap.add_argument('--cpu-rays', type=int, default=1440)
-    ap.add_argument('--cpu-cores', type=int, default=16)
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
+                    help='strong (default): the rays of ONE volume are shared out over the ranks and gathered on rank 0; '
+                         'weak: every rank simulates a whole volume of its own')
+    ap.add_argument('--config', choices=sorted(WORKLOADS), default='C4', help='reference configuration (C4 = the headline volume)')
+    ap.add_argument('--cpu-rays', type=int, default=0, help='rays of the CPU baseline sample (0 = sized to 10-30 s of CPU work)')
+    ap.add_argument('--cpu-cores', type=int, default=0, help='workers of the CPU baseline (0 = the CPUs this job may use)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--doppler', type=int, choices=[0, 1, 2, 3], default=2,
+    ap.add_argument('--no-host-copy', action='store_true', help='skip the second measurement with the outputs delivered to host memory')
+    ap.add_argument('--no-overlap', action='store_true', help='N > 1: wait for each gather before the next volume starts')
+    ap.add_argument('--doppler', type=int, choices=[0, 1, 2, 3], default=None,
                     help='doppler.scheme of the workload (3 = full Doppler spectrum, needs --microphysics 1)')
-    ap.add_argument('--microphysics', type=int, choices=[1, 2], default=2,
+    ap.add_argument('--microphysics', type=int, choices=[1, 2], default=None,
                     help='2 = the headline 2-moment workload; 1 = the same volume with 1-moment input (3 classes)')
-    ap.add_argument('--gh', type=int, default=3, help='Gauss-Hermite nodes per direction: 3 = the 9 sub-beams of the headline '
+    ap.add_argument('--gh', type=int, default=None, help='Gauss-Hermite nodes per direction: 3 = the 9 sub-beams of the headline '
                     'workload, 9 = the 81 sub-beams of the literal CH_PPI_lema.yml (secondary run)')
+    ap.add_argument('--turbulence', type=int, choices=[0, 1], default=0, help='C5: turbulence broadening of the spectrum')
     ap.add_argument('--batch-units', type=int, default=0, help='positions per internal batch (0 = library default)')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
-    args = ap.parse_args()
+    ap.add_argument('--stub-engine', action='store_true',
+                    help='CPU stand-in for the kernels over gloo: rehearses launch, sharding and gather without GPUs (result INVALID)')
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    wl = WORKLOADS[args.config]
+    doppler = wl['dop'] if args.doppler is None else args.doppler
+    microphysics = wl['mp'] if args.microphysics is None else args.microphysics
+    n_gh = wl['gh'] if args.gh is None else args.gh
+    strong = args.scaling == 'strong'
 
-    from cosmo_pol_amd import synthetic as syn
-    conf = workload_config(args.small, args.doppler, args.microphysics, args.gh)
-    azs, elv = volume_rays(args.small)
+    from tests import synthetic as syn
+    conf = workload_config(args.small, doppler, microphysics, n_gh, args.config, args.turbulence)
+    azs, elv, n_sweeps, rays_per_sweep = volume_rays(args.small, args.config)
     shape = (80, 774, 1158) if not args.small else (24, 200, 240)
-    model = syn.synthetic_model(*shape, scheme=args.microphysics, seed=20161111 + (rank if args.scaling == 'weak' else 0),
-                                res=(0.01, 0.01) if not args.small else (0.05, 0.05))
-    tabs = {h: syn.synthetic_lut(h, 5.6) for h in syn.hydrom_types(args.microphysics)}
+    model = tabs = None
+    if not args.stub_engine:
+        model = syn.synthetic_model(*shape, scheme=microphysics, seed=20161111 + (0 if strong else rank),
+                                    res=(0.01, 0.01) if not args.small else (0.05, 0.05))
+        if args.turbulence:
+            z = np.asarray(model['zlev'], dtype=np.float64)
+            model['fields']['EDR'] = (2e-3 * np.exp(-z / 4000.) * (1.5 + np.sin(z / 700.))).astype('float32')
+        tabs = {h: syn.synthetic_lut(h, wl['freq']) for h in syn.hydrom_types(microphysics)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(conf, model, tabs, azs, elv, args.cpu_rays, args.cpu_cores)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.stub_engine:
+        cores, allowed, cpu_model = host_cpu_share()
+        if args.cpu_cores:
+            cores = args.cpu_cores
+        # about 20 s of CPU work: the C4 path costs ~0.19 core-seconds per ray, the Doppler spectrum ~20 x that
+        per_ray = 0.19 * (n_gh * n_gh / 9.) * (20. if doppler == 3 else 1.)
+        n_cpu = args.cpu_rays or int(max(cores, min(len(azs), 20. * cores / per_ray)))
+        cpu = cpu_baseline(conf, model, tabs, azs, elv, n_cpu, cores, allowed, cpu_model)
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    from cosmo_pol_amd import engine, _lib
-    from cosmo_pol_amd.lut import Lookup_table
-    eng = engine.Engine(conf, device=local_rank)
-    eng.upload_luts({h: Lookup_table.from_arrays(*t) for h, t in tabs.items()})
-    eng.upload_model(model['fields'], model['zlev'], model['proj_info'], model['resolution'])
-    eng.set_gauss_hermite()
-    del model
-    ctx = eng.ctx
-    if args.batch_units:
-        ctx.set_batch_units(args.batch_units)
-
-    if args.scaling == 'strong' and world > 1:
-        n_az = len(np.unique(azs))
-        sel = np.array([i for i in range(len(azs)) if (i % n_az) % world == rank])
-        my_az, my_el = azs[sel], elv[sel]
+    from cosmo_pol_amd import parallel
+    if args.stub_engine:
+        runner = StubRunner(conf)
+        if world > 1:
+            dist.init_process_group('gloo')
     else:
-        my_az, my_el = azs, elv
-    R, G = len(my_az), eng.n_gates
-    dev = torch.device('cuda', local_rank)
-    az_t = torch.tensor(my_az, dtype=torch.float64, device=dev)
-    el_t = torch.tensor(my_el, dtype=torch.float64, device=dev)
-    obs_t = torch.empty((_lib.N_OBS, R, G), dtype=torch.float32, device=dev)
-    rvel_t = torch.empty((R, G), dtype=torch.float64, device=dev)
-    mask_t = torch.empty((R, G), dtype=torch.float64, device=dev)
-    lat_t = torch.empty((R, G), dtype=torch.float64, device=dev)
-    lon_t = torch.empty((R, G), dtype=torch.float64, device=dev)
-    dist_t = torch.empty((R, G), dtype=torch.float32, device=dev)
-    hgt_t = torch.empty((R, G), dtype=torch.float32, device=dev)
-    stat_t = torch.zeros((R,), dtype=torch.int32, device=dev)
-    gather_list = None
-    if args.scaling == 'strong' and world > 1 and rank == 0:
-        gather_list = [torch.empty_like(obs_t) for _ in range(world)]
-    torch.cuda.synchronize()
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        runner = GpuRunner(conf, model, tabs, local_rank, args.batch_units)
+    del model
+    G = runner.n_gates
 
-    def P(t, typ):
-        return ctypes.cast(t.data_ptr(), typ)
+    shards = parallel.all_shards(n_sweeps, rays_per_sweep, world) if strong else [np.arange(len(azs))] * world
+    mine = shards[rank]
+    R = len(mine)
+    az_t, el_t = runner.angles(azs[mine], elv[mine])
+    gather = strong and world > 1
+    n_buf = 2 if gather and not args.no_overlap else 1
+    bufs = [runner.outputs(R) for _ in range(n_buf)]
+    structs = [runner.struct(b) for b in bufs]
+    gathers = [parallel.VolumeGather(shards, len(azs)) for _ in range(n_buf)] if gather else None
+    pending = [False] * n_buf
+    t_compute = t_gather = 0.
+    volume = None
 
-    def step():
-        o = _lib.CpolOutputs(P(obs_t, _lib.c_float_p), P(rvel_t, _lib.c_double_p), P(mask_t, _lib.c_double_p),
-                             P(lat_t, _lib.c_double_p), P(lon_t, _lib.c_double_p), P(dist_t, _lib.c_float_p),
-                             P(hgt_t, _lib.c_float_p), P(stat_t, _lib.c_int_p))
-        ctx.run_rays_dev(az_t.data_ptr(), el_t.data_ptr(), R, o)
-        if args.scaling == 'strong' and world > 1:
-            ctx.synchronize()
-            dist.gather(obs_t, gather_list, dst=0)
+    def fields_of(t):
+        from collections import OrderedDict
+        f = OrderedDict(obs=t['obs'].permute(1, 0, 2))
+        for k in ('rvel', 'mask', 'lat', 'lon', 'dist', 'height'):
+            f[k] = t[k]
+        return f
+
+    def finish(i):
+        nonlocal t_gather, volume
+        if gather and pending[i]:
+            t0 = time.perf_counter()
+            v = gathers[i].finish()
+            if not args.stub_engine:
+                torch.cuda.synchronize()
+            t_gather += time.perf_counter() - t0
+            pending[i] = False
+            if v is not None:
+                volume = v
+
+    def step(k):
+        nonlocal t_compute
+        i = k % n_buf
+        finish(i)                                  # the buffer's previous volume has left
+        t0 = time.perf_counter()
+        runner.run(az_t, el_t, structs[i])
+        if gather:
+            runner.sync()
+            t_compute += time.perf_counter() - t0
+            gathers[i].start(fields_of(bufs[i]), async_op=not args.no_overlap)
+            pending[i] = True
+            if args.no_overlap:
+                finish(i)
 
     def sync_all():
-        ctx.synchronize()
-        torch.cuda.synchronize()
+        for i in range(n_buf):
+            finish(i)
+        runner.sync()
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     sync_all()
-    assert int(stat_t.abs().sum().item()) == 0, "a ray left the model domain"
-    ctx.timing_enable(True)
+    assert int(bufs[0]['ray_status'].abs().sum().item()) == 0, "a ray left the model domain"
+    timed = not args.stub_engine
+    if timed:
+        runner.ctx.timing_enable(True)
+    t_compute = t_gather = 0.
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        step(k)
     sync_all()
     dt = time.perf_counter() - t0
-    tim = ctx.timing_read()
-    ctx.timing_enable(False)
+    tim = None
+    if timed:
+        tim = runner.ctx.timing_read()
+        runner.ctx.timing_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, t_compute, t_gather], dtype=torch.float64, device=runner.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    finite = float(torch.isfinite(obs_t[0]).float().mean().item())
-    finite_rvel = float(torch.isfinite(rvel_t).float().mean().item()) if args.doppler else None
+        dt, t_compute, t_gather = (float(x) for x in t.tolist())
+    last = bufs[(args.steps - 1) % n_buf] if args.steps else bufs[0]
+    finite = float(torch.isfinite(last['obs'][0]).float().mean().item())
+    finite_rvel = float(torch.isfinite(last['rvel']).float().mean().item()) if doppler else None
+    gathered_ok = None
+    if gather and rank == 0 and volume is not None:
+        # rank 0's own rays sit at their positions of the gathered volume
+        gathered_ok = bool(torch.equal(volume['rvel'][torch.as_tensor(mine, device=volume['rvel'].device)].nan_to_num(),
+                                       last['rvel'].nan_to_num())) and tuple(volume['obs'].shape) == (len(azs), 9, G)
+
+    # second measurement at N = 1: the same steps with the outputs delivered to (pinned) host memory, the copy of
+    # one batch of rays running beside the kernels of the next
+    host = None
+    if timed and world == 1 and not args.no_host_copy:
+        hb = runner.outputs(R, pinned_host=True)
+        hs = runner.struct(hb)
+        az_np, el_np = np.ascontiguousarray(azs[mine]), np.ascontiguousarray(elv[mine])
+        if not args.batch_units:
+            runner.ctx.set_batch_units(max(1 << 20, (R * runner.n_sub * G + 3) // 4))      # four batches per volume
+        runner.run_host(az_np, el_np, hs)
+        runner.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            runner.run_host(az_np, el_np, hs)
+        dth = time.perf_counter() - t0
+        same = all(torch.equal(hb[k].nan_to_num(), last[k].cpu().nan_to_num()) for k in ('obs', 'rvel', 'mask', 'lat', 'height'))
+        host = {'ms_per_step_host': dth / args.steps * 1e3, 'value_host': len(azs) * G * args.steps / dth,
+                'host_outputs_equal_device_outputs': bool(same),
+                'host_bytes_per_step': int(sum(v.numel() * v.element_size() for v in hb.values()))}
+        if not args.batch_units:
+            runner.ctx.set_batch_units(32 << 20)
 
     if rank == 0:
-        gates_per_step = (len(azs) * G) * (world if args.scaling == 'weak' else 1)
-        ms_int = tim['ms']['integrate'] / max(1, tim['launches']['integrate'])
-        # the two Doppler scheme-2 columns count for k_integrate only when they ride on its units; with
-        # 2-moment input they are units of their own on the vector ALUs (stage integrate_dop)
-        flop_unit = FLOP_PER_UNIT + (FLOP_PER_UNIT_DOP2 if args.doppler == 2 and tim['doppler_units'] == 0 else 0)
-        # Of a unit's 1024 terms only those whose float32 N(D) is not an exact zero are evaluated (the library
-        # counts them); `achieved` prices the evaluated terms against the matrix-core peak, `algorithmic` is the
-        # rate of the reference's full 1024-term contraction that the same launch stands for.
-        evaluated = tim['evaluated_unit_diameters'] / (1024. * tim['valid_units']) if tim['valid_units'] else 1.
-        flop_alg_launch = flop_unit * tim['valid_units'] / max(1, tim['launches']['integrate'])
-        flop_per_launch = flop_alg_launch * evaluated
-        achieved = flop_per_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
-        algorithmic = flop_alg_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath) and not args.small:
-            traffic = json.load(open(tpath)).get('k_integrate_hbm_bytes_per_launch')
+        gates_per_step = len(azs) * G * (1 if strong else world)
+        roofline = stage = None
+        extra = {}
+        if tim is not None:
+            ms_int = tim['ms']['integrate'] / max(1, tim['launches']['integrate'])
+            # the two Doppler scheme-2 columns count for k_integrate only when they ride on its units; with
+            # 2-moment input they are units of their own on the vector ALUs (stage integrate_dop)
+            flop_unit = FLOP_PER_UNIT + (FLOP_PER_UNIT_DOP2 if doppler == 2 and tim['doppler_units'] == 0 else 0)
+            # Of a unit's 1024 terms only those whose float32 N(D) is not an exact zero are evaluated (the library
+            # counts them); `achieved` prices the evaluated terms against the matrix-core peak, `algorithmic` is the
+            # rate of the reference's full 1024-term contraction that the same launch stands for.
+            evaluated = tim['evaluated_unit_diameters'] / (1024. * tim['valid_units']) if tim['valid_units'] else 1.
+            flop_alg_launch = flop_unit * tim['valid_units'] / max(1, tim['launches']['integrate'])
+            flop_per_launch = flop_alg_launch * evaluated
+            achieved = flop_per_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
+            algorithmic = flop_alg_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath) and not args.small and args.config == 'C4' and world == 1:
+                traffic = json.load(open(tpath)).get('k_integrate_hbm_bytes_per_launch')
+            roofline = {'bound': 'mfma', 'kernel': 'k_integrate', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                        'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
+                        'launches': tim['launches']['integrate'], 'evaluated_fraction': evaluated,
+                        'algorithmic_tflops': algorithmic}
+            stage = {k: v / args.steps for k, v in tim['ms'].items()}
+            extra = {'valid_units_per_step': tim['valid_units'] / args.steps,
+                     'doppler_units_per_step': tim['doppler_units'] / args.steps,
+                     'doppler_evaluated_fraction': (tim['doppler_unit_diameters'] / (1024. * tim['doppler_units'])
+                                                    if tim['doppler_units'] else None)}
+        invalid = ' [SMALL DEBUG RUN - INVALID]' if args.small else ''
+        invalid += ' [STUB ENGINE, NO KERNELS - INVALID]' if args.stub_engine else ''
+        scan = '%d elevations x %d azimuths' % (n_sweeps, rays_per_sweep) if wl['kind'] == 'ppi' else \
+            'RHI, %d azimuth(s) x %d elevations' % (n_sweeps, rays_per_sweep)
         line = {
             'metric': METRIC, 'value': gates_per_step * args.steps / dt, 'unit': 'gates/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'CH_PPI_lema volume: 20 elevations x 360 azimuths x %d gates, COSMO-1 grid '
-                                   '%dx%dx%d, %d-moment (%d classes), %dx%d Gauss-Hermite (%d sub-beams), attenuation on, '
-                                   'Doppler scheme %d%s' % (G, shape[2], shape[1], shape[0], args.microphysics,
-                                                            args.microphysics + 2, args.gh, args.gh, eng.ctx.n_sub,
-                                                            args.doppler,
-                                                            ' [SMALL DEBUG RUN - INVALID]' if args.small else ''),
-                       'rays_per_rank': R, 'gates': G, 'sub_beams': eng.ctx.n_sub, 'classes': args.microphysics + 2,
-                       'parallelism': 'rays sharded, %d rank(s)' % world},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_integrate', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
-                         'launches': tim['launches']['integrate'], 'evaluated_fraction': evaluated,
-                         'algorithmic_tflops': algorithmic},
-            'stage_ms_per_step': {k: v / args.steps for k, v in tim['ms'].items()},
-            'valid_units_per_step': tim['valid_units'] / args.steps,
-            'doppler_units_per_step': tim['doppler_units'] / args.steps,
-            'doppler_evaluated_fraction': (tim['doppler_unit_diameters'] / (1024. * tim['doppler_units'])
-                                           if tim['doppler_units'] else None),
+            'config': {'workload': '%s (%s): %s x %d gates, COSMO-1 grid %dx%dx%d, %d-moment (%d classes), %dx%d '
+                                   'Gauss-Hermite (%d sub-beams), attenuation on, Doppler scheme %d%s%s'
+                                   % (wl['name'], args.config, scan, G, shape[2], shape[1], shape[0], microphysics,
+                                      microphysics + 2, n_gh, n_gh, runner.n_sub, doppler,
+                                      ' + turbulence' if args.turbulence else '', invalid),
+                       'rays_per_rank': R, 'gates': G, 'sub_beams': runner.n_sub, 'classes': microphysics + 2,
+                       'parallelism': ('one volume, rays block-cyclic by azimuth over %d rank(s), one gather of all outputs to rank 0'
+                                       if strong else 'one volume per rank, %d rank(s), no collective') % world},
+            'roofline': roofline,
+            'stage_ms_per_step': stage,
             'finite_zh_fraction': finite, 'finite_rvel_fraction': finite_rvel,
             'cpu_baseline': cpu,
         }
+        line.update(extra)
+        if host:
+            line.update(host)
+        if gather:
+            line.update({'compute_ms_per_step_max_rank': t_compute / args.steps * 1e3,
+                         'gather_wait_ms_per_step_max_rank': t_gather / args.steps * 1e3,
+                         'gather_overlapped': not args.no_overlap, 'gathered_volume_ok': gathered_ok})
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

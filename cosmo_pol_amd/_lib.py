@@ -269,7 +269,8 @@ class Context(object):
         self.n_sub = len(a)
 
     # -- hot path ------------------------------------------------------------------
-    def run_rays(self, azimuth, elevation, raise_on_domain=True):
+    def run_rays(self, azimuth, elevation, raise_on_domain=True, check_status=True):
+        """check_status=False leaves every per-ray status (domain, refraction table) to the caller."""
         az = np.ascontiguousarray(azimuth, dtype=np.float64)
         el = np.ascontiguousarray(elevation, dtype=np.float64)
         R, G = len(az), self.n_gates
@@ -286,6 +287,8 @@ class Context(object):
                         iptr(out['ray_status']), dptr(out['dspectrum']) if self.doppler == 3 else None)
         rc = self.lib.cpol_run_rays(self.h, R, az.ctypes.data, el.ctypes.data, C.byref(o))
         self._check(rc, 'cpol_run_rays')
+        if not check_status:
+            return out
         if raise_on_domain and (out['ray_status'] == ERR_DOMAIN).any():
             self._check(ERR_DOMAIN, 'cpol_run_rays')
         if (out['ray_status'] == ERR_REFRACTION).any():

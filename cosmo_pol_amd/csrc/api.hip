@@ -200,6 +200,8 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
         for (float *q : owned) if (q) (void)hipFree(q);
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->valid_host) (void)hipHostFree(ctx->valid_host);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -697,8 +699,34 @@ static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)
 // The hot path for n_rays rays.  no_alloc = false: the workspaces are the ctx's grow-only heap buffers and the
 // rays go through in batches.  no_alloc = true (cpol_run_rays_static): ctx->arena is set, every workspace is a
 // piece of the static scratch, azimuth / elevation are device arrays used in place, and nothing is allocated.
+// Queue the device-to-host copies of rays [r0, r0 + nr) of every requested output on the copy stream, behind
+// the event that marks the end of their batch on the compute stream.
+static int copy_batch_to_host(cpol_ctx *ctx, const cpol_outputs &d, const cpol_outputs &h, int n_rays, int r0, int nr,
+                              hipEvent_t done)
+{
+    const size_t G = ctx->cfg.n_gates, RG = (size_t)n_rays * G, o = (size_t)r0 * G, n = (size_t)nr * G;
+    hipStream_t s = ctx->copy_stream;
+    HIPCHK(ctx, hipStreamWaitEvent(s, done, 0));
+    if (h.obs)
+        for (int f = 0; f < CPOL_N_OBS; f++)
+            HIPCHK(ctx, hipMemcpyAsync(h.obs + f * RG + o, d.obs + f * RG + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h.rvel && d.rvel) HIPCHK(ctx, hipMemcpyAsync(h.rvel + o, d.rvel + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h.dspectrum && d.dspectrum)
+        HIPCHK(ctx, hipMemcpyAsync(h.dspectrum + o * ctx->n_vel, d.dspectrum + o * ctx->n_vel, n * ctx->n_vel * sizeof(double),
+                                   hipMemcpyDeviceToHost, s));
+    if (h.mask) HIPCHK(ctx, hipMemcpyAsync(h.mask + o, d.mask + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h.lat) HIPCHK(ctx, hipMemcpyAsync(h.lat + o, d.lat + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h.lon) HIPCHK(ctx, hipMemcpyAsync(h.lon + o, d.lon + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (h.dist) HIPCHK(ctx, hipMemcpyAsync(h.dist + o, d.dist + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h.height) HIPCHK(ctx, hipMemcpyAsync(h.height + o, d.height + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h.ray_status) HIPCHK(ctx, hipMemcpyAsync(h.ray_status + r0, d.ray_status + r0, nr * sizeof(int), hipMemcpyDeviceToHost, s));
+    return CPOL_OK;
+}
+
+// host (may be NULL): host buffers that receive the outputs batch by batch, the copy of one batch on a second
+// stream beside the kernels of the next.
 static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
-                         cpol_outputs *out, bool no_alloc)
+                         cpol_outputs *out, bool no_alloc, const cpol_outputs *host = nullptr)
 {
     ClassTable ct;
     TRY(build_class_table(ctx, ct, !no_alloc));
@@ -754,6 +782,9 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
     ModelView mv;
     build_model_view(ctx, mv);
     const double *wsub = ctx->quad_dev + 2 * B;
+    if (host && !ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    int prev_r0 = -1, prev_nr = 0, n_batch = 0;
+    hipEvent_t prev_done = nullptr;
     for (int r0 = 0; r0 < n_rays; r0 += rays_per_batch) {
         int nr = n_rays - r0 < rays_per_batch ? n_rays - r0 : rays_per_batch;
         long nu = (long)nr * per_ray;
@@ -775,9 +806,26 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
         TRY(run_physics(ctx, ct, nr, B, G, (const float *)w.b_vals.p, nu_max, (const float *)w.b_E.p,
                         (const signed char *)w.b_mask.p, wsub, (const double *)w.b_phi.p,
                         out->obs, RG, r0, out->mask, out->rvel, out->dspectrum));
+        if (host) {
+            // this batch's kernels are queued: now hand the previous batch to the copy stream (a copy into
+            // pageable memory blocks the host, which by then has given the GPU its next batch)
+            if ((size_t)n_batch == ctx->copy_events.size()) {
+                hipEvent_t e;
+                HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ctx->copy_events.push_back(e);
+            }
+            hipEvent_t done = ctx->copy_events[n_batch++];
+            HIPCHK(ctx, hipEventRecord(done, ctx->stream));
+            if (prev_done) TRY(copy_batch_to_host(ctx, *out, *host, n_rays, prev_r0, prev_nr, prev_done));
+            prev_done = done; prev_r0 = r0; prev_nr = nr;
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     if (!ctx->cfg.doppler_scheme) out->rvel = nullptr;
+    if (host && prev_done) {
+        TRY(copy_batch_to_host(ctx, *out, *host, n_rays, prev_r0, prev_nr, prev_done));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    }
     return CPOL_OK;
 }
 
@@ -819,23 +867,15 @@ extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, c
                              cpol_outputs *host)
 {
     if (!host) return CPOL_ERR_ARG;
+    TRY(check_ready(ctx, true, true));
+    if (n_rays == 0) return CPOL_OK;
+    if (n_rays < 0 || !azimuth || !elevation) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the outputs are produced in ctx-owned device buffers and leave for the host batch by batch
     cpol_outputs d;
     memset(&d, 0, sizeof(d));
-    TRY(cpol_run_rays_dev(ctx, n_rays, azimuth, elevation, &d));
-    if (n_rays == 0) return CPOL_OK;
-    const size_t RG = (size_t)n_rays * ctx->cfg.n_gates;
-    hipStream_t s = ctx->stream;
-    if (host->obs) HIPCHK(ctx, hipMemcpyAsync(host->obs, d.obs, CPOL_N_OBS * RG * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (host->rvel && d.rvel) HIPCHK(ctx, hipMemcpyAsync(host->rvel, d.rvel, RG * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (host->dspectrum && d.dspectrum)
-        HIPCHK(ctx, hipMemcpyAsync(host->dspectrum, d.dspectrum, RG * ctx->n_vel * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (host->mask) HIPCHK(ctx, hipMemcpyAsync(host->mask, d.mask, RG * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (host->lat) HIPCHK(ctx, hipMemcpyAsync(host->lat, d.lat, RG * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (host->lon) HIPCHK(ctx, hipMemcpyAsync(host->lon, d.lon, RG * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (host->dist) HIPCHK(ctx, hipMemcpyAsync(host->dist, d.dist, RG * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (host->height) HIPCHK(ctx, hipMemcpyAsync(host->height, d.height, RG * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (host->ray_status) HIPCHK(ctx, hipMemcpyAsync(host->ray_status, d.ray_status, n_rays * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    TRY(run_rays_impl(ctx, n_rays, azimuth, elevation, &d, false, host));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     timing_collect(ctx);
     return CPOL_OK;
 }

@@ -104,6 +104,8 @@ struct ObsParams {
 struct cpol_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;         // device-to-host copies of cpol_run_rays, beside the kernels of the next batch
+    std::vector<hipEvent_t> copy_events;       // one per batch: its kernels have finished
     std::string err;
     bool have_cfg = false, have_model = false;
     cpol_config cfg;

@@ -103,33 +103,64 @@ class RadarOperator(object):
             st.eng.set_refraction(None)
         rank, world = _dist_info()
         n_total = len(azs)
-        if world > 1:
-            from . import parallel
-            idx = parallel.shard_indices(n_sweeps, rays_per_sweep, rank, world)
+        if world == 1:
+            out = ctx.run_rays(azs, els)      # raises IndexError when a gate leaves the model domain
+            fields = {n: out['obs'][i] for i, n in enumerate(OBS_NAMES)}
+            fields['RVEL'] = out['rvel']
+            if dscheme in (3, 4):
+                fields['DSPECTRUM'] = out['dspectrum']              # [n_rays, n_gates, n_velocity_bins]
+            extra = {'mask': out['mask'], 'lat': out['lat'], 'lon': out['lon'], 'height': out['height']}
         else:
-            idx = np.arange(n_total)
-        out = ctx.run_rays(azs[idx], els[idx])      # raises IndexError when a gate leaves the model domain
-        fields = {n: out['obs'][i] for i, n in enumerate(OBS_NAMES)}
-        fields['RVEL'] = out['rvel']
-        if dscheme in (3, 4):
-            fields['DSPECTRUM'] = out['dspectrum']              # [n_rays, n_gates, n_velocity_bins]
-        extra = {'mask': out['mask'], 'lat': out['lat'], 'lon': out['lon'], 'height': out['height']}
-        if world > 1:
-            import torch
-            from . import parallel
-            g = lambda a: parallel.gather_rays(torch.as_tensor(a), idx, n_total)
-            fields = {k: g(v) for k, v in fields.items()}
-            extra = {k: g(v) for k, v in extra.items()}
-            if rank != 0:
+            # one process per GPU: every rank simulates its share of the rays (the reference's pool.map over rays,
+            # radar_operator.py:253-256) and rank 0 receives the volume in one gather
+            vol = self._run_sharded(ctx, azs, els, n_sweeps, rays_per_sweep, rank, world)
+            if vol is None:
                 return None
-            fields = {k: v.numpy() for k, v in fields.items()}
-            extra = {k: v.numpy() for k, v in extra.items()}
+            fields = {n: vol['obs'][:, i] for i, n in enumerate(OBS_NAMES)}
+            fields['RVEL'] = vol['rvel']
+            if dscheme in (3, 4):
+                fields['DSPECTRUM'] = vol['dspectrum']
+            extra = {k: vol[k] for k in ('mask', 'lat', 'lon', 'height')}
         ranges = st.eng.n_gates and np.arange(cfg.CONFIG['radar']['radial_resolution'] / 2,
                                               cfg.CONFIG['radar']['range'], cfg.CONFIG['radar']['radial_resolution'])
         return SimulatedRadar(scan_type, els, azs, ranges, fields, extra['mask'], extra['lat'], extra['lon'],
                               extra['height'], n_sweeps, rays_per_sweep, self.get_pos_and_time(),
                               fixed_angles=sweep_elev if scan_type == 'ppi' else sweep_az,
                               varray=constants.VARRAY)
+
+    def _run_sharded(self, ctx, azs, els, n_sweeps, rays_per_sweep, rank, world):
+        """Rays block-cyclic over the ranks, one gather of every output field to rank 0.  With the RCCL backend
+        the outputs stay in device memory until rank 0 has the whole volume; with gloo (CPU tensors) they go
+        through the host.  Returns {name: numpy array [n_rays, ...]} on rank 0, None elsewhere."""
+        from collections import OrderedDict
+        import torch
+        import torch.distributed as dist
+        from . import parallel
+        from ._lib import ERR_DOMAIN, ERR_REFRACTION, CosmoPolError
+        shards = parallel.all_shards(n_sweeps, rays_per_sweep, world)
+        idx = shards[rank]
+        if dist.get_backend() == 'nccl':
+            dev = torch.device('cuda', self.device)
+            local, status = parallel.run_rays_device(ctx, azs[idx], els[idx], dev)
+            status = status.cpu().numpy()
+        else:
+            dev = None
+            out = ctx.run_rays(azs[idx], els[idx], check_status=False)
+            local = OrderedDict((k, torch.as_tensor(out[k])) for k in ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height', 'dspectrum')
+                                if k in out)
+            if 'rvel' not in local:
+                local['rvel'] = torch.full(tuple(local['mask'].shape), float('nan'), dtype=torch.float64)
+            local['obs'] = local['obs'].permute(1, 0, 2)
+            status = out['ray_status']
+        # every rank learns of a failed ray anywhere, so that all of them raise instead of waiting in the gather
+        if parallel.any_rank((status == ERR_DOMAIN).any(), dev):
+            raise IndexError('ERROR: RADAR DOMAIN IS NOT ENTIRELY CONTAINED IN COSMO SIMULATION DOMAIN: ABORTING')
+        if parallel.any_rank((status == ERR_REFRACTION).any(), dev):
+            raise CosmoPolError('cpol_run_rays: the refraction table has no profile for the elevation of some rays')
+        vol = parallel.gather_volume(local, shards, len(azs))
+        if vol is None:
+            return None
+        return {k: v.cpu().numpy() for k, v in vol.items()}
 
     def get_GPM_swath(self, GPM_file, band='Ku'):
         """radar_operator.py:350-424: the swath of a GPM DPR overpass.  GPM_file: the DPR HDF5 file (needs h5py) or

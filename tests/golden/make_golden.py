@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shim                      # noqa: E402
-from cosmo_pol_amd import synthetic as syn       # noqa: E402
+from tests import synthetic as syn               # noqa: E402
 
 LUT_NE, LUT_NT = 8, 12      # reduced e / t axes keep the regenerated tables small
 
@@ -257,7 +257,7 @@ def gen_refl():
 
 
 def gen_cut():
-    from cosmo_pol_amd import synthetic  # noqa: F401
+    from tests import synthetic  # noqa: F401
     out = {}
     rng = np.random.default_rng(31)
     zh = (10 ** rng.uniform(-3, 4, 64)).astype('float32')

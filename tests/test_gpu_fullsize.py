@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import bench                                                   # noqa: E402  workload definition only
-from cosmo_pol_amd import _lib, engine, synthetic as syn      # noqa: E402
+from cosmo_pol_amd import _lib, engine                        # noqa: E402
+from tests import synthetic as syn                             # noqa: E402
 from cosmo_pol_amd.lut import Lookup_table                    # noqa: E402
 from oracle import cosmo_oracle as O                           # noqa: E402
 from tests import util                                         # noqa: E402
@@ -25,7 +26,7 @@ OBS = _lib.OBS_NAMES
 def volume():
     import copy
     conf = copy.deepcopy(bench.workload_config(False, doppler=2))
-    azs, elv = bench.volume_rays(False)
+    azs, elv = bench.volume_rays(False)[:2]
     model = syn.synthetic_model(80, 774, 1158, scheme=2, seed=20161111, res=(0.01, 0.01))
     tabs = {h: syn.synthetic_lut(h, 5.6) for h in syn.hydrom_types(2)}
     eng = engine.Engine(conf, device=0)

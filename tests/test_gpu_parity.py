@@ -6,10 +6,10 @@ compared bit for bit."""
 import numpy as np
 import pytest
 
-from cosmo_pol_amd import _lib, engine, synthetic as syn
+from cosmo_pol_amd import _lib, engine
 from cosmo_pol_amd.lut import Lookup_table
 from oracle import cosmo_oracle as O
-from tests import util
+from tests import synthetic as syn, util
 
 pytestmark = pytest.mark.gpu
 

@@ -212,7 +212,8 @@ def test_lut_packing_and_lookups_vs_reference():
 
 
 def test_lut_file_roundtrip_and_frequency_interpolation(tmp_path):
-    from cosmo_pol_amd import read_lut, synthetic as syn
+    from cosmo_pol_amd import read_lut
+    from tests import synthetic as syn
     from cosmo_pol_amd.lut import Lookup_table
     folder = str(tmp_path)
     tabs = {}

@@ -125,7 +125,7 @@ def test_ex_bemas_refraction_and_geodesic():
 
 
 def test_interp_c_restatement():
-    from cosmo_pol_amd import synthetic as syn
+    from tests import synthetic as syn
     g = util.golden('interp')
     nz, ny, nx, scheme, seed = [int(v) for v in g['seed_model']]
     m = syn.synthetic_model(nz=nz, ny=ny, nx=nx, scheme=scheme, seed=seed, llc=(-1.0, -0.8), res=(0.05, 0.04), ztop=9000.)

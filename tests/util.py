@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from cosmo_pol_amd import synthetic as syn
+from tests import synthetic as syn
 from oracle import cosmo_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
