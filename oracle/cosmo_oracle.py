@@ -896,6 +896,27 @@ def get_radar_beam_trilin(list_vars, azimuth, dist, heights, cfg):
     return lats, lons, beams
 
 
+def integrate_GH_pts(list_beams):
+    """interpolation/interpolation.py:21-51 (diagnostic mode): GH-weighted, NaN-aware sum of every model
+    variable over the sub-beams."""
+    num_beams = len(list_beams)
+    out = {}
+    for k in list_beams[0].values.keys():
+        out[k] = [float('nan')]
+        sum_weights = 0
+        for b in list_beams:
+            sum_weights += b.GH_weight
+        for b in list_beams:
+            out[k] = nansum_arr(out[k], b.values[k] * b.GH_weight / sum_weights)
+    mask = np.zeros(num_beams,)
+    for b in list_beams:
+        mask = sum_arr(mask, b.mask)
+    mask /= float(num_beams)
+    mask[np.logical_and(mask >= 0, mask < 1)] = 0
+    c = list_beams[int(num_beams / 2)]
+    return Beam(out, mask, c.lats_profile, c.lons_profile, c.dist_profile, c.heights_profile)
+
+
 def get_profiles_GH(dic_variables, azimuth, elevation, cfg, list_refraction=0):
     """interpolation/interpolation.py:53-308, integration scheme 1; refraction scheme 1 unless the caller
     hands in list_refraction = [(S, H, E) per vertical node] as the reference's parameter of that name allows

@@ -484,8 +484,9 @@ def test_geolocate_vs_oracle():
             d = np.abs(geo['coords'][r, b].view(np.int32) - rot.view(np.int32))
             assert d.max() <= 1
             n_bad += int((d != 0).sum())
-    # float64 libm differences may flip a float32 rounding now and then, never more
-    assert n_bad <= 0.001 * geo['dist'].size * 5
+    # float64 libm differences may flip a float32 rounding now and then (measured on 900 000 positions of the
+    # benchmark volume: one value in 4.5 million), never more
+    assert n_bad <= 2
 
 
 def test_turbulence_whole_path_and_fallback(capsys):
@@ -683,6 +684,32 @@ def test_radar_operator_three_element_sensitivity():
         ok = ~np.isnan(want_db)
         assert np.abs(got[ok] - want_db[ok]).max() < 0.01
     assert cut > 0 and kept > 0          # the threshold bites somewhere along the rays, not everywhere
+
+
+def test_radar_operator_diagnostic_mode():
+    """diagnostic_mode=True (radar_operator.py:245-246): the sub-beam averages of the interpolated model variables
+    (interpolation.integrate_GH_pts, interpolation.py:21-51) join the output fields."""
+    from cosmo_pol_amd import RadarOperator
+    conf, m, dic, luts = _api_setup(2, 3, 3)
+    op = RadarOperator(conf, diagnostic_mode=True)
+    op.load_model_file(dic)
+    op.set_lut(2, luts)
+    els, azs = [1.5, 12.0], [15., 200., 310.]
+    radar = op.get_PPI(els, azimuths=azs)
+    plain = RadarOperator(conf)
+    plain.load_model_file(dic)
+    plain.set_lut(2, luts)
+    assert 'T' not in plain.get_PPI(els, azimuths=azs).fields
+    seen = 0
+    for s, el in enumerate(els):
+        for i, az in enumerate(azs):
+            with np.errstate(all='ignore'):
+                want = O.integrate_GH_pts(O.get_profiles_GH(oracle_model_vars(m), az, el, conf))
+            for k in ('T', 'U', 'QR_v', 'QNS_v', 'RHO'):
+                got = radar.get_field(s, k)[i].filled(np.nan)
+                util.assert_close(got, np.asarray(want.values[k], dtype=np.float64), rtol=1e-6, atol=1e-30, name=k)
+                seen += int((got != 0).sum())
+    assert seen > 100
 
 
 def test_radar_operator_rhi_doppler_spectrum():
