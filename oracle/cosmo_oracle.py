@@ -669,6 +669,29 @@ def get_doppler_spectrum(beam, hydros, luts, cfg, consts, get_refl=get_refl_np):
     return refl
 
 
+def spectrum_open_bins(list_beams, cfg):
+    """[gates, velocity bins] True where some sub-beam's first or last spectrum row sits (doppler_sz.py:344-367):
+    the outer diameter edge of those two rows is shared with no other row, so a table term on the other side of it
+    is not in the neighbouring bin but outside the spectrum.  (Test helper: tells the spectrum checks where a
+    last-bit difference of an edge cannot be a mere exchange between neighbours.)"""
+    consts = radar_constants(cfg)
+    hydros = _doppler_hydros(cfg)
+    n = max(len(b.dist_profile) for b in list_beams)
+    out = np.zeros((n, len(consts['VARRAY'])), dtype=bool)
+    for beam in list_beams:
+        with np.errstate(all='ignore'):
+            rho_corr = (beam.values['RHO'] / beam.values['RHO'][0]) ** 0.5
+        for i in range(len(beam.dist_profile)):
+            if beam.mask[i] != 0:
+                continue
+            with np.errstate(all='ignore'):
+                _, _, idx = get_diameter_from_rad_vel(hydros, beam.GH_pt[0], beam.elev_profile[i], beam.values['U'][i],
+                                                      beam.values['V'][i], beam.values['W'][i], rho_corr[i], consts['VARRAY'])
+            if len(idx):
+                out[i, idx[0]] = out[i, idx[-1]] = True
+    return out
+
+
 def get_turb_std(ranges, EDR, cfg):
     """doppler/doppler_sz.py:308-321 with true division (the reference's (3/2) and (1/3) are Python-2 integer
     divisions, which would make every standard deviation 1): Doviak and Zrnic's two regimes of the turbulence
