@@ -167,7 +167,7 @@ class Context(object):
     def synchronize(self):
         self._check(self.lib.cpol_synchronize(self.h), 'cpol_synchronize')
 
-    STAGES = ['geom', 'interp', 'prep_sort', 'integrate', 'observables', 'integrate_dop']
+    STAGES = ['geom', 'interp', 'prep_sort', 'integrate', 'observables', 'integrate_dop', 'spectrum']
 
     def timing_enable(self, on=True):
         self._check(self.lib.cpol_timing_enable(self.h, int(on)), 'cpol_timing_enable')

@@ -610,8 +610,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
             d2.img[h] = v.table; d2.xq[h] = v.xq; d2.n_t[h] = v.n_t;
         }
     }
-    StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
     if (ctx->cfg.doppler_scheme == 3) {
+        StageTimer ts_(ctx, CPOL_ST_SPECTRUM);
         if (ctx->n_vel < 2) return fail(ctx, CPOL_ERR_STATE, "doppler_scheme 3: cpol_set_velocity_bins has not been called");
         // the spectrum needs the radar cross-section only: 4 KB per table node instead of the 48 KB of all twelve
         // components, built once per uploaded table
@@ -654,6 +654,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         launch_spectrum(ctx->stream, ct, sp, nr, nu, vals, plane, elev, mask, wsub, phi, ctx->varray_dev,
                         ctx->rawptr_dev, ctx->rawptr_dev + CPOL_MAX_CLASSES, spectrum, rvel_out, ray0);
     }
+    StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
     launch_observables(ctx->stream, op, nr, nu, (const cpol_key_t *)ctx->w->b_key.p, (const double *)ctx->w->b_coef.p,
                        (const float *)ctx->w->b_psd.p, mask, wsub, (const double *)ctx->w->b_vr.p, obs, obs_plane, ray0,
                        mask_out, rvel_out, d2, spectrum, ctx->n_vel);

@@ -1,7 +1,7 @@
 """Process-wide engine cache: the reference keeps configuration, model state and lookup tables
 in module globals (utilities/cfg.py:9, radar_operator.py:71-84); the GPU context plays that role
 here.  One engine per (device); model / tables are re-uploaded only when the caller hands in a
-different object."""
+different object or asks for it (force=True; in-place edits of the arrays are not detected otherwise)."""
 import copy
 
 import numpy as np
@@ -36,21 +36,22 @@ def get_engine(device=0, doppler=None, sensitivity_cut=False):
     return st
 
 
-def ensure_luts(st, lut_sz):
-    key = (id(lut_sz), st.eng.conf['microphysics']['scheme'])
-    if st.lut_key != key:
+def ensure_luts(st, lut_sz, force=False):
+    # the uploaded object itself is kept and compared with `is`: an id() can be reused by a later object once the
+    # earlier one has been freed
+    scheme = st.eng.conf['microphysics']['scheme']
+    if force or st.lut_key is None or st.lut_key[0] is not lut_sz or st.lut_key[1] != scheme:
         st.eng.upload_luts(lut_sz)
-        st.lut_key = key
+        st.lut_key = (lut_sz, scheme)
 
 
-def ensure_model(st, dic_variables):
-    key = id(dic_variables)
-    if st.model_key != key:
+def ensure_model(st, dic_variables, force=False):
+    if force or st.model_key is not dic_variables:
         first = next(iter(dic_variables.values()))
         fields = {k: v.data for k, v in dic_variables.items()}
         st.eng.upload_model(fields, first.attributes['z-levels'], first.attributes['proj_info'],
                             first.attributes['resolution'])
-        st.model_key = key
+        st.model_key = dic_variables
 
 
 def ensure_quadrature(st):

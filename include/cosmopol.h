@@ -110,9 +110,9 @@ int  cpol_synchronize(cpol_ctx *ctx);
  * quantity its arithmetic scales with; doppler_units = units of the Doppler scheme-2
  * moments that were integrated separately because their PSD differs (stage INTEGRATE_DOP;
  * 0 when the moments ride on the polarimetric units). */
-#define CPOL_N_STAGES 6
+#define CPOL_N_STAGES 7
 enum cpol_stage { CPOL_ST_GEOM = 0, CPOL_ST_INTERP, CPOL_ST_PREP_SORT, CPOL_ST_INTEGRATE, CPOL_ST_OBSERVABLES,
-                  CPOL_ST_INTEGRATE_DOP };
+                  CPOL_ST_INTEGRATE_DOP, CPOL_ST_SPECTRUM /* Doppler spectrum, doppler_scheme 3 */ };
 int cpol_timing_enable(cpol_ctx *ctx, int on);          /* also resets the totals */
 int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_launches[CPOL_N_STAGES],
                      double *valid_units, double *doppler_units);

@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import ref_shim                      # noqa: E402
 from tests import synthetic as syn               # noqa: E402
+from tests.util import PROFILE_CASES             # noqa: E402
 
 LUT_NE, LUT_NT = 8, 12      # reduced e / t axes keep the regenerated tables small
 
@@ -283,17 +284,6 @@ def synthetic_antenna():
     lin = np.exp(-ang ** 2 / (2 * sig ** 2)) + 10 ** -2.6 * np.exp(-(np.abs(ang) - 2.8) ** 2 / (2 * 0.4 ** 2)) \
         + 10 ** -3.3 * np.exp(-(np.abs(ang) - 4.9) ** 2 / (2 * 0.5 ** 2))
     return ang, 10 * np.log10(lin) / 2.          # the reference squares the one-way gain (interpolation.py:124)
-
-
-PROFILE_CASES = {
-    'gh_1x1': dict(integration={'scheme': 1, 'nh_GH': 1, 'nv_GH': 1, 'weight_threshold': 1.}),
-    'gh_3x3': dict(integration={'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.}),
-    'gh_3x9_thr': dict(integration={'scheme': 1, 'nh_GH': 3, 'nv_GH': 9, 'weight_threshold': 0.999}),
-    'multigauss': dict(integration={'scheme': 2, 'nr_GH': 3, 'na_GL': 5, 'weight_threshold': 1.,
-                                    'antenna_params': np.array([[0., 0., 0.62], [-26., 2.8, 0.4], [-26., -2.8, 0.4]])}),
-    'legendre_antenna': dict(integration={'scheme': 3, 'nh_GH': 5, 'nv_GH': 3, 'weight_threshold': 1.}),
-    'gautschi': dict(integration={'scheme': 5, 'nh_GH': 3, 'nv_GH': 5, 'weight_threshold': 0.9999}),
-}
 
 
 def gen_profiles():

@@ -869,7 +869,7 @@ def test_profiles_vs_reference_run(name, tmp_path):
     it, but the sub-beam set, refraction, masks and the interpolated values along the beams are)."""
     from cosmo_pol_amd import interpolation, cfg as pcfg, model as pmodel, runtime
     from cosmo_pol_amd.constants import constants
-    from tests.golden.make_golden import PROFILE_CASES
+    from tests.util import PROFILE_CASES
     g = util.golden('profiles')
     conf = O.make_config(radar={'coords': [46.0, 8.5, 1500.], 'radial_resolution': 500., 'range': 20000.,
                                 'frequency': 5.6, '3dB_beamwidth': 1.45},

@@ -74,3 +74,16 @@ def assert_close(a, b, rtol, atol=0.0, name=""):
         i = np.argmax(err)
         raise AssertionError("%s: max violation at %d: got %r want %r (rtol %g atol %g)" %
                              (name, i, a[fin][i], b[fin][i], rtol, atol))
+
+
+# integration settings of the 'profiles' golden (tests/golden/make_golden.py: gen_profiles), shared by the generator
+# and the GPU test that reads the fixture
+PROFILE_CASES = {
+    'gh_1x1': dict(integration={'scheme': 1, 'nh_GH': 1, 'nv_GH': 1, 'weight_threshold': 1.}),
+    'gh_3x3': dict(integration={'scheme': 1, 'nh_GH': 3, 'nv_GH': 3, 'weight_threshold': 1.}),
+    'gh_3x9_thr': dict(integration={'scheme': 1, 'nh_GH': 3, 'nv_GH': 9, 'weight_threshold': 0.999}),
+    'multigauss': dict(integration={'scheme': 2, 'nr_GH': 3, 'na_GL': 5, 'weight_threshold': 1.,
+                                    'antenna_params': np.array([[0., 0., 0.62], [-26., 2.8, 0.4], [-26., -2.8, 0.4]])}),
+    'legendre_antenna': dict(integration={'scheme': 3, 'nh_GH': 5, 'nv_GH': 3, 'weight_threshold': 1.}),
+    'gautschi': dict(integration={'scheme': 5, 'nh_GH': 3, 'nv_GH': 5, 'weight_threshold': 0.9999}),
+}
