@@ -56,7 +56,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_run_rays_static', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -84,6 +84,8 @@ def load():
     lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
     lib.cpol_timing_work.argtypes = [vp, c_double_p, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
+    lib.cpol_set_term_cutoff.argtypes = [vp, C.c_int]
+    lib.cpol_get_term_cutoff.argtypes = [vp, c_float_p]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
                                       c_float_p, c_float_p, c_float_p, c_double_p]
@@ -182,6 +184,16 @@ class Context(object):
         return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
                 'valid_units': vu.value, 'doppler_units': du.value, 'evaluated_unit_diameters': wk.value,
                 'doppler_unit_diameters': wd.value}
+
+    def set_term_cutoff(self, certified=True):
+        self._check(self.lib.cpol_set_term_cutoff(self.h, int(bool(certified))), 'cpol_set_term_cutoff')
+
+    def get_term_cutoff(self):
+        """{class letter: exponent E}: terms with N(D) < 2^-E N(D_0) are left out of the PSD integration (150 = only
+        exact float32 zeros)."""
+        e = (C.c_float * 4)()
+        self._check(self.lib.cpol_get_term_cutoff(self.h, e), 'cpol_get_term_cutoff')
+        return {k: float(e[i]) for k, i in CLASS_INDEX.items() if e[i] > 0}
 
     def set_batch_units(self, n):
         self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')

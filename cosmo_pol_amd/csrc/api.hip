@@ -37,6 +37,8 @@ static int ensure(cpol_ctx *ctx, cpol_ctx::Buf &b, size_t bytes)
 
 #define TRY(x) do { int rc_ = (x); if (rc_ != CPOL_OK) return rc_; } while (0)
 
+static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build);
+
 // ---- stage timing -------------------------------------------------------------------
 static hipEvent_t next_event(cpol_ctx *ctx)
 {
@@ -130,6 +132,31 @@ extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters,
     return CPOL_OK;
 }
 
+extern "C" int cpol_set_term_cutoff(cpol_ctx *ctx, int certified)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    ctx->certified_cutoff = certified != 0;
+    for (auto &l : ctx->lut) l.image_ncol = 0;          // images and certificates are redone at the next set-up / run
+    if (ctx->have_cfg) {
+        bool all = true;
+        const int n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
+        for (int h = 0; h < n_cls; h++) all = all && ctx->lut[h].present;
+        if (all) {
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            ClassTable ct;
+            return build_class_table(ctx, ct, true);
+        }
+    }
+    return CPOL_OK;
+}
+
+extern "C" int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES])
+{
+    if (!ctx || !exponent) return CPOL_ERR_ARG;
+    for (int h = 0; h < CPOL_MAX_CLASSES; h++) exponent[h] = ctx->lut[h].present ? ctx->lut[h].cut_e - 2.f : 0.f;
+    return CPOL_OK;
+}
+
 extern "C" int cpol_set_batch_units(cpol_ctx *ctx, long max_units)
 {
     if (!ctx || max_units < 1) return CPOL_ERR_ARG;
@@ -192,6 +219,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->quad_dev) (void)hipFree(ctx->quad_dev);
     if (ctx->varray_dev) (void)hipFree(ctx->varray_dev);
     if (ctx->work_dev) (void)hipFree(ctx->work_dev);
+    if (ctx->cert_dev) (void)hipFree(ctx->cert_dev);
     if (ctx->refr_keys) (void)hipFree(ctx->refr_keys);
     if (ctx->refr_tab) (void)hipFree(ctx->refr_tab);
     if (ctx->rawptr_dev) (void)hipFree((void *)ctx->rawptr_dev);
@@ -468,6 +496,22 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
                                        L.psd_dop.nu, L.psd_dop.alpha, L.psd_dop.beta, (double)(float)xref_of(L, L.psd_dop.nu));
             }
             HIPCHK(ctx, hipGetLastError());
+            // term cutoff of the class: the smallest exponent its tables are certified for, else exact zeros only
+            L.cut_e = 152.f;
+            {
+                bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
+                for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
+                if (ctx->certified_cutoff && asc && L.psd.nu > 0.) {
+                    if (!ctx->cert_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->cert_dev, sizeof(float)));
+                    const double cand[] = {48., 56., 64., 72., 80., 96., 112., 128.};
+                    for (double e : cand) {
+                        const float worst = cut_certificate(ctx->stream, L.raw, L.d_axis, nslice, L.psd.mu, L.psd.nu,
+                                                            xref_of(L, L.psd.nu), shared ? 1 : 0, L.psd_dop.mu, L.psd_dop.alpha,
+                                                            L.psd_dop.beta, e, ctx->cert_dev);
+                        if (worst <= 3.7252903e-09f) { L.cut_e = (float)(e + 2.); break; }      // 2^-28
+                    }
+                }
+            }
             L.image_ncol = tag;
         }
         LutView &v = ct.lut[h];
@@ -483,6 +527,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
         bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
         for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
         ct.cut_ok[h] = (asc && L.psd.nu > 0.) ? 1 : 0;
+        ct.cut_e[h] = L.cut_e;
         ct.dop_cut_ok[h] = (asc && L.psd_dop.nu > 0.) ? 1 : 0;
         ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)L.axis_step : 0.f;
@@ -539,6 +584,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->w->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_coef, nslots * sizeof(double)));
     TRY(ensure(ctx, ctx->w->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
+    TRY(ensure(ctx, ctx->w->b_nq, (size_t)nu * ct.n_cls));                             // quad count of every listed unit
     TRY(ensure(ctx, ctx->w->b_rank, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->w->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
@@ -578,7 +624,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
     launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->w->b_cbkt.p, (int *)ctx->w->b_sorted.p,
-                     (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, count_work ? ctx->work_dev : nullptr);
+                     (unsigned char *)ctx->w->b_nq.p, (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, count_work ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);

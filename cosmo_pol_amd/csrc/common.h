@@ -31,6 +31,7 @@ struct LutDev {
     float  d0 = 0;                 // first diameter
     std::vector<float> d_host;     // the diameter axis as uploaded
     int    image_ncol = 0;         // what `table` was last built for
+    float  cut_e = 152.f;          // term cutoff exponent the tables of this class are certified for (see k_cut_certificate)
     cpol_psd psd, psd_dop;
 };
 
@@ -67,6 +68,7 @@ struct ClassTable {
     PsdView psd[CPOL_MAX_CLASSES];
     PsdView dop[CPOL_MAX_CLASSES];
     int     cut_ok[CPOL_MAX_CLASSES];          // D^nu ascending along the diameter axis
+    float   cut_e[CPOL_MAX_CLASSES];           // terms with N(D) < 2^-(cut_e - 2) N(D_0) are left out (152: exact float32 zeros only)
     int     dop_cut_ok[CPOL_MAX_CLASSES];      // same for the Doppler PSD's nu
 };
 
@@ -135,7 +137,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     struct Work {
         Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-            b_sorted, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+            b_sorted, b_nq, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
             o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     };
     Work heap, arena_work;
@@ -145,6 +147,8 @@ struct cpol_ctx {
     size_t arena_cap = 0, arena_off = 0;
     size_t max_batch_units = (size_t)32 << 20;     // (ray x sub-beam x gate) positions per batch
     // optional stage timing (hipEvents on ctx->stream) and work counters
+    bool   certified_cutoff = true;               // term cutoffs below the exact-zero one where the tables carry a certificate
+    float *cert_dev = nullptr;                    // result word of k_cut_certificate
     unsigned long long *work_dev = nullptr;       // 2 x 64 partial counts of unit x 16-diameter steps evaluated by k_integrate / k_integrate_dop (timing only)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -188,8 +192,10 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, int *sorted, const float2 *lam, float *psd_out,
-                      unsigned long long *work);
+                      const int *chunk_off, const int *chunk_bucket, int *sorted, unsigned char *nq_sorted, const float2 *lam,
+                      float *psd_out, unsigned long long *work);
+float cut_certificate(hipStream_t s, const float *raw, const float *d_axis, long nslice, double mu, double nu, double x_ref,
+                      int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, float *worst_dev);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
                           const int *chunk_off, const int *chunk_bucket, const int *sorted, const float2 *lam,
                           const double *n0d, float2 *dop_out, long slot0, unsigned long long *work);

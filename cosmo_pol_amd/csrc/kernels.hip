@@ -649,6 +649,76 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
                        ncol, mu, nu, with_dop, zero_pol, mu_d, alpha_d, beta_d, x_ref);
 }
 
+// Certificate for a term cutoff below the exact-zero one.  A unit with slope l2 leaves out the quads whose first
+// D^nu - x_ref exceeds cut_e / l2.  For every table node, every column and every quad boundary c = 16 (q + 1) the
+// kernel evaluates the worst case of the units that stop there - l2 = cut_e / x_c, the smallest slope with that
+// cutoff, for which the omitted terms weigh most - and forms
+//     sum_{d >= c} |B'[d][j]| 2^(-l2 x_d)  /  sum_d |B'[d][j]| 2^(-l2 x_d)
+// (within one cutoff interval the omitted terms decay faster with l2 than the kept ones, so the left end is the
+// supremum).  The maximum over nodes, columns and boundaries goes to *worst; the host accepts cut_e when it is
+// below 2^-28, a sixteenth of float32's resolution of the sum.
+__global__ __launch_bounds__(256)
+void k_cut_certificate(const float *__restrict__ raw, const float *__restrict__ d_axis, double mu, double nu, double x_ref,
+                       int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, unsigned *__restrict__ worst)
+{
+    constexpr int NJ = 14;
+    __shared__ double s_red[4][2 * NJ];
+    const long sl = blockIdx.x;
+    const int c = 16 * ((int)blockIdx.y + 1);
+    const double xc = pow((double)d_axis[c], nu) - x_ref;
+    if (!(xc > 0.)) return;
+    const double l2 = cut_e / xc;
+    double tot[NJ], tail[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { tot[j] = 0.; tail[j] = 0.; }
+    for (int d = threadIdx.x; d < 1024; d += 256) {
+        const double D = (double)d_axis[d];
+        const double n = exp2(-l2 * (pow(D, nu) - x_ref));
+        const double dm = pow(D, mu) * n;
+        const float *src = raw + (sl * 1024 + d) * CPOL_N_SZ;
+        double w[NJ];
+#pragma unroll
+        for (int j = 0; j < CPOL_N_SZ; j++) w[j] = fabs((double)src[j]) * dm;
+        w[12] = 0.; w[13] = 0.;
+        if (with_dop) {
+            const double rcs = fabs(2 * M_PI * ((((double)src[0] - src[1]) - src[2]) + src[3])) * pow(D, mu_d) * n;
+            w[12] = rcs; w[13] = rcs * alpha_d * pow(D, beta_d);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; j++) { tot[j] += w[j]; if (d >= c) tail[j] += w[j]; }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        for (int off = 32; off > 0; off >>= 1) { tot[j] += __shfl_xor(tot[j], off); tail[j] += __shfl_xor(tail[j], off); }
+        if (lane == 0) { s_red[wv][j] = tot[j]; s_red[wv][NJ + j] = tail[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.;
+        for (int j = 0; j < NJ; j++) {
+            const double t = s_red[0][j] + s_red[1][j] + s_red[2][j] + s_red[3][j];
+            const double tl = s_red[0][NJ + j] + s_red[1][NJ + j] + s_red[2][NJ + j] + s_red[3][NJ + j];
+            if (t > 0.) r = fmax(r, tl / t);
+            else if (tl > 0. || t != t) r = 1.;          // nothing kept, or not a number: no certificate
+        }
+        const float rf = (float)(r * 1.000001);           // rounded up; non-negative floats order like their bit patterns
+        atomicMax(worst, __float_as_uint(rf));
+    }
+}
+
+float cut_certificate(hipStream_t s, const float *raw, const float *d_axis, long nslice, double mu, double nu, double x_ref,
+                      int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, float *worst_dev)
+{
+    if (hipMemsetAsync(worst_dev, 0, sizeof(float), s) != hipSuccess) return 1.f;
+    hipLaunchKernelGGL(k_cut_certificate, dim3((unsigned)nslice, 63), dim3(256), 0, s, raw, d_axis, mu, nu, x_ref, with_dop,
+                       mu_d, alpha_d, beta_d, cut_e, (unsigned *)worst_dev);
+    float w = 1.f;
+    if (hipMemcpyAsync(&w, worst_dev, sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) return 1.f;
+    if (hipStreamSynchronize(s) != hipSuccess) return 1.f;
+    return w;
+}
+
 // Compact image of the Doppler scheme-2 columns for units with a PSD of their own (k_integrate_dop):
 //   img[sl][d] = D^nu_d - D_0^nu_d  (d < 1024),   img[sl][1024 + 2 d + c] = rcs D^mu_d (c = 0), rcs v(D) D^mu_d (c = 1)
 // i.e. 12 KB per (e, t) node; the two moments of a diameter sit side by side for packed arithmetic.  The exponent is taken
@@ -736,12 +806,14 @@ __device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, 
     return true;
 }
 
-// D^nu beyond which exp2(-l2 * D^nu) is an exact float32 zero (the exponent passes -150 even after the
-// roundings of the quotient and of the product): terms past it add nothing to a float32 sum.  +inf (no
+// D^nu beyond which a unit's terms are left out: exp2(-l2 * D^nu) < 2^-(cut_e - 2).  cut_e = 152: the exponent
+// passes -150 even after the roundings of the quotient and of the product, N(D) is an exact float32 zero and the
+// terms past it add nothing to a float32 sum.  A smaller cut_e is used only for a class whose tables carry a
+// certificate (k_cut_certificate) that the terms past it stay below 2^-28 of the sum for every lambda.  +inf (no
 // cutoff) for a lambda that is not a positive finite number, so that its NaN / inf results are kept.
-__device__ inline float psd_cutoff_x(float l2)
+__device__ inline float psd_cutoff_x(float l2, float cut_e = 152.f)
 {
-    return (l2 > 0.f && l2 < __builtin_inff()) ? 152.f / l2 : __builtin_inff();
+    return (l2 > 0.f && l2 < __builtin_inff()) ? cut_e / l2 : __builtin_inff();
 }
 
 // Position of the run of equal keys this lane belongs to inside its wave.
@@ -998,8 +1070,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, (NC == 12 ? 3 : 2) * (INTEG_THREADS / 256))
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                 const int *__restrict__ chunk_bucket, int *sorted, const float2 *__restrict__ lam, float *__restrict__ psd_out,
-                 unsigned long long *__restrict__ work)
+                 const int *__restrict__ chunk_bucket, int *sorted, unsigned char *nq_sorted, const float2 *__restrict__ lam,
+                 float *__restrict__ psd_out, unsigned long long *__restrict__ work)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
@@ -1035,6 +1107,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const LutView lv = hk < ct.n_cls ? ct.lut[hk] : ct.lut_dop[hk - ct.n_cls];
     const float gstep = hk < ct.n_cls ? ct.pol_geo_step[hk] : 0.f;     // 4 x diameter step when N(D) is geometric
     const bool cut_ok = hk < ct.n_cls && ct.cut_ok[hk];                // D^nu ascending: N(D) = 0 past a unit's cutoff
+    const float cut_e = hk < ct.n_cls ? ct.cut_e[hk] : 152.f;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
@@ -1058,7 +1131,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     for (int t = 0; t < UPT; t++) {
         nqu[t] = 64; myrank[t] = 0;
         if (cut_ok) {
-            const float xc = psd_cutoff_x(lu[t].x + lu[t].y);
+            const float xc = psd_cutoff_x(lu[t].x + lu[t].y, cut_e);
             int c = 0;
 #pragma unroll
             for (int step = 64; step >= 1; step >>= 1)
@@ -1084,7 +1157,11 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int nq_chunk = s_hist[65];
 #pragma unroll
     for (int t = 0; t < UPT; t++)
-        if (tid + t * INTEG_THREADS < cnt) sorted[start + s_hist[nqu[t]] + myrank[t]] = myslot[t];
+        if (tid + t * INTEG_THREADS < cnt) {
+            const int pos = start + s_hist[nqu[t]] + myrank[t];
+            sorted[pos] = myslot[t];
+            nq_sorted[pos] = (unsigned char)nqu[t];          // the unit's own quad count, next to its list entry
+        }
     __syncthreads();
 
     // ---- stage the quads the chunk needs: straight 16-byte copy of the pre-permuted image ----
@@ -1130,22 +1207,18 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         int ua = g0 * 16 + j, ub = ua + 16;
         // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
         float2 la = make_float2(0.f, 0.f), lb = la;
-        if (ua < cnt) la = lam[sorted[start + ua]];
-        if (ub < cnt) lb = lam[sorted[start + ub]];
+        int nqa = 0, nqb = 0;           // quads each of the lane's two units takes part in
+        if (ua < cnt) { la = lam[sorted[start + ua]]; nqa = nq_sorted[start + ua]; }
+        if (ub < cnt) { lb = lam[sorted[start + ub]]; nqb = nq_sorted[start + ub]; }
         const f32x2 nhi = {-la.x, -lb.x}, nlo = {-la.y, -lb.y};
         double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
-        // quads up to the last one in which any of the pass's units still has a nonzero float32 N(D): the count
-        // of its last unit in cutoff order (lane 15's second unit, or the chunk's last)
-        int nq = 64;
-        if (cut_ok) {
-            const int ulast = min(g0 * 16 + 31, cnt - 1);
-            const float2 ll = ulast >= g0 * 16 + 16 ? lb : la;
-            const float xc = __shfl(psd_cutoff_x(ll.x + ll.y), ulast & 15);
-            nq = 0;
-#pragma unroll
-            for (int step = 64; step >= 1; step >>= 1)
-                if (nq + step <= 64 && lds[LDS_X + (nq + step - 1) * 16] <= xc) nq += step;
-        }
+        // The pass runs up to the quad count of its last unit in cutoff order (lane 15's second unit, or the
+        // chunk's last); up to the count of its first unit every unit takes part, beyond it a unit's N(D) is
+        // set to zero once its own count is reached, so that a unit's sums cover its own quads whatever units
+        // share its pass.
+        const int ulast = min(g0 * 16 + 31, cnt - 1);
+        const int nq = __shfl(ulast >= g0 * 16 + 16 ? nqb : nqa, ulast & 15);
+        const int nq_lo = __shfl(nqa, 0);
         wsum += (unsigned)nq * (unsigned)min(cnt - g0 * 16, 32);
         if (gstep > 0.f) {
             // nu = 1 on a uniform diameter axis: N(D) is a geometric sequence.  A lane's four values of a quad
@@ -1158,11 +1231,16 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             const f32x2 R2v = Rv * Rv;
             const f32x2 R4v = R2v * R2v;
             // one seed group: quads q0 .. q0+3
+            const int nqa4 = (nqa + 3) & ~3, nqb4 = (nqb + 3) & ~3, lo4 = (nq_lo + 3) & ~3;
             auto seed_group = [&](int q0, f32x4 &acca, f32x4 &accb) {
                 const float x0 = X4[q0 * 4].x;
                 const f32x2 x2 = {x0, x0};
                 const f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);
                 f32x2 n0 = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+                if (q0 >= lo4) {          // a unit that has had its seed groups: zero seed, zero terms
+                    n0.x = q0 < nqa4 ? n0.x : 0.f;
+                    n0.y = q0 < nqb4 ? n0.y : 0.f;
+                }
                 f32x2 n1 = n0 * Rv, n2 = n0 * R2v;
                 f32x2 n3 = n1 * R2v;
 #pragma unroll
@@ -1199,6 +1277,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         } else {
             auto quad = [&](int qd, f32x4 &acca, f32x4 &accb) {
                 float4 bq = B4[bbase + qd * bstride];
+                const bool tail = qd >= nq_lo;         // wave-uniform: some units of the pass are past their own count
                 float4 xq = X4[qd * 4];
                 const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
                 const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
@@ -1211,6 +1290,13 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                     f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);   // one rounding of -(hi+lo)*x
                     na[s4] = __builtin_amdgcn_exp2f(p.x);
                     nb_[s4] = __builtin_amdgcn_exp2f(p.y);
+                }
+                if (tail) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+                        na[s4] = qd < nqa ? na[s4] : 0.f;
+                        nb_[s4] = qd < nqb ? nb_[s4] : 0.f;
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1255,17 +1341,17 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 }
 
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, int *sorted, const float2 *lam, float *psd_out,
-                      unsigned long long *work)
+                      const int *chunk_off, const int *chunk_bucket, int *sorted, unsigned char *nq_sorted, const float2 *lam,
+                      float *psd_out, unsigned long long *work)
 {
     if (max_chunks <= 0) return;
     max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
     if (ct.ncol == 12)
         hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, lam, psd_out, work);
+                           chunk_bucket, sorted, nq_sorted, lam, psd_out, work);
     else
         hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, lam, psd_out, work);
+                           chunk_bucket, sorted, nq_sorted, lam, psd_out, work);
 }
 
 // =============================================================================

@@ -123,6 +123,16 @@ int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_l
  * all 1024 terms in float64, scattering_sz.py:95-103).  doppler_unit_diameters (may be NULL): the same for
  * stage INTEGRATE_DOP, where a unit whose N0 is an exact zero needs no term at all. */
 int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters);
+/* Which terms of the PSD integration (scattering_sz.py:95-103: all 1024 diameters, float64) are evaluated.  The
+ * terms whose N(D) = exp(-lambda D^nu) underflows to an exact float32 zero are always left out.  With
+ * certified != 0 (the default) a class may stop earlier, at N(D) < 2^-E N(D_0), E in {48 .. 128}: when its tables
+ * are uploaded the library computes, for every table node, scattering component and stopping point, the largest
+ * share of the sum that any lambda can leave beyond that point, and takes the smallest E for which this share is
+ * below 2^-28 (a sixteenth of float32's resolution) everywhere; tables that admit no such E keep the exact-zero
+ * rule.  certified = 0 switches to the exact-zero rule for every class.  cpol_get_term_cutoff returns E per class
+ * (150 = exact zeros only, 0 = no table uploaded).  No counterpart in the reference. */
+int cpol_set_term_cutoff(cpol_ctx *ctx, int certified);
+int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES]);
 /* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
  * workspace the library allocates (default 32 Mi positions, about 26 GB with 2-moment input and Doppler scheme 2,
  * allocated only as far as a call needs it; at most 128 Mi). */

@@ -163,6 +163,58 @@ def test_observables_with_extreme_contents(scheme, dscheme):
         util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
 
 
+def test_certified_term_cutoff():
+    """The PSD integration stops a unit where its N(D) falls below 2^-E N(D_0); E < 150 only for classes whose tables
+    carry the library's certificate that the omitted terms stay below 2^-28 of the sum.  Contents over 10 decades:
+    the certified run equals the exact-zero run to float32 rounding and both meet the oracle; a table that grows too
+    fast along the diameter axis gets no certificate and keeps the exact-zero rule."""
+    conf = O.make_config(microphysics={'scheme': 2}, attenuation={'correction': 0}, doppler={'scheme': 0},
+                         radar={'radial_resolution': 500., 'frequency': 5.6})
+    eng = make_engine(conf)
+    cut = eng.ctx.get_term_cutoff()
+    assert sorted(cut) == ['G', 'H', 'R', 'S'] and all(48. <= e <= 128. for e in cut.values()), cut
+    beams = syn.synthetic_beams(300, 9, 2, seed=31337, res=500., zero_frac=0.1)
+    rng = np.random.default_rng(5)
+    for b in beams:
+        for k, v in b['values'].items():
+            if k.startswith('Q') and k.endswith('_v'):
+                v *= (10. ** rng.uniform(-8, 2, v.shape)).astype(np.float32)
+    obs1, _, _ = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    eng.ctx.set_term_cutoff(False)
+    assert all(e == 150. for e in eng.ctx.get_term_cutoff().values())
+    obs0, _, _ = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    eng.ctx.set_term_cutoff(True)
+    assert eng.ctx.get_term_cutoff() == cut
+    for n in ('ZH', 'ZV', 'AH', 'AV', 'RHOHV'):
+        a, b = obs1[OBS.index(n)].astype(np.float64), obs0[OBS.index(n)].astype(np.float64)
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+        ok = ~np.isnan(b)
+        assert np.abs(a[ok] / b[ok] - 1).max() <= 2.5e-7, n          # two float32 roundings
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(beams), util.oracle_luts(2, 5.6), conf)
+    check_obs(obs1, want.values, 'certified cutoff', 500.)
+    check_obs(obs0, want.values, 'exact-zero cutoff', 500.)
+    # snow table growing by 28 more decades along its diameter axis (41 in all): no exponent up to 128 is safe for
+    # that class, the exact-zero rule still is
+    tabs = dict(util.synthetic_lut_arrays(2, 5.6))          # a copy: the helper's dictionary is shared between tests
+    e, t, d, tab = tabs['S']
+    tabs['S'] = (e, t, d, (tab * 1e-20 * (10. ** (1.4 * d.astype(np.float64)))[None, None, :, None]).astype(np.float32))
+    assert np.isfinite(tabs['S'][3]).all()
+    eng2 = engine.Engine(conf, device=0)
+    eng2.upload_luts({h: Lookup_table.from_arrays(*v) for h, v in tabs.items()})
+    cut2 = eng2.ctx.get_term_cutoff()
+    assert cut2['S'] == 150. and cut2['R'] == cut['R'], cut2
+    obs2, _, _ = eng2.ctx.observables_from_beams(*beams_to_arrays(beams))
+    with np.errstate(all='ignore'):
+        want2 = O.get_radar_observables(util.oracle_beams(beams), {h: O.Lut(*v) for h, v in tabs.items()}, conf)
+    # (values of this table are astronomically large: the relative bar only)
+    for n in ('ZH', 'ZV', 'AH', 'AV', 'RHOHV'):
+        a, b = obs2[OBS.index(n)].astype(np.float64), np.asarray(want2.values[n], dtype=np.float64)
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+        ok = ~np.isnan(b)
+        assert np.abs(a[ok] / b[ok] - 1).max() <= 1e-5, n
+
+
 def test_observables_with_descending_diameter_axis():
     """A table whose diameter axis runs from large to small: no cutoff ordering applies (the library only uses it on
     ascending axes) and the exponent reference is the smallest diameter wherever it sits; dD = D[1] - D[0] is
