@@ -584,7 +584,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->w->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_coef, nslots * sizeof(double)));
     TRY(ensure(ctx, ctx->w->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
-    TRY(ensure(ctx, ctx->w->b_nq, (size_t)nu * ct.n_cls));                             // quad count of every listed unit
+    TRY(ensure(ctx, ctx->w->b_urec, (size_t)nu * ct.n_cls * sizeof(float4)));          // the chunks' units in cutoff order
     TRY(ensure(ctx, ctx->w->b_rank, nslots * sizeof(int)));
     TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->w->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
@@ -623,8 +623,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     const long max_chunks = (nu * ct.n_cls + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb_pol;
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
-    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->w->b_cbkt.p, (int *)ctx->w->b_sorted.p,
-                     (unsigned char *)ctx->w->b_nq.p, (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, count_work ? ctx->work_dev : nullptr);
+    launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->w->b_cbkt.p, (const int *)ctx->w->b_sorted.p,
+                     (float4 *)ctx->w->b_urec.p, (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, count_work ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);

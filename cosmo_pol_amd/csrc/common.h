@@ -137,7 +137,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     struct Work {
         Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-            b_sorted, b_nq, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+            b_sorted, b_urec, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
             o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
     };
     Work heap, arena_work;
@@ -192,7 +192,7 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, int *sorted, unsigned char *nq_sorted, const float2 *lam,
+                      const int *chunk_off, const int *chunk_bucket, const int *sorted, float4 *urec, const float2 *lam,
                       float *psd_out, unsigned long long *work);
 float cut_certificate(hipStream_t s, const float *raw, const float *d_axis, long nslice, double mu, double nu, double x_ref,
                       int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, float *worst_dev);

@@ -1070,7 +1070,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NC>
 __global__ __launch_bounds__(INTEG_THREADS, (NC == 12 ? 3 : 2) * (INTEG_THREADS / 256))
 void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                 const int *__restrict__ chunk_bucket, int *sorted, unsigned char *nq_sorted, const float2 *__restrict__ lam,
+                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, float4 *urec, const float2 *__restrict__ lam,
                  float *__restrict__ psd_out, unsigned long long *__restrict__ work)
 {   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
@@ -1082,9 +1082,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     // chunk-local counting sort of the units by the number of quads (16 diameters) their N(D) survives
     // (its 65 counters borrow the start of the table area, which is filled only afterwards: with them in a
     // region of their own the workgroup would pass the LDS size at which three fit a CU)
-    // The sorted order itself replaces the chunk's segment of the unit list in global memory (every thread reads
-    // its entries before any is rewritten): the list's order inside a chunk means nothing to its other reader,
-    // k_integrate_dop, which orders the units itself.
+    // The sorted order goes to global memory as one 16-byte record per unit (slope, own quad count, slot), written
+    // next to each other in cutoff order: a pass then fetches its 32 units with coalesced loads, no permutation
+    // lives in LDS.
     int *s_hist = (int *)lds;
 
     // XCD-aware chunk order: the workgroups of one XCD (blockIdx % 8) take runs of INTEG_XCD_RUN consecutive
@@ -1158,9 +1158,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 #pragma unroll
     for (int t = 0; t < UPT; t++)
         if (tid + t * INTEG_THREADS < cnt) {
-            const int pos = start + s_hist[nqu[t]] + myrank[t];
-            sorted[pos] = myslot[t];
-            nq_sorted[pos] = (unsigned char)nqu[t];          // the unit's own quad count, next to its list entry
+            // the chunk's units in cutoff order, one 16-byte record each: slope (hi, lo), own quad count, slot
+            urec[start + s_hist[nqu[t]] + myrank[t]] =
+                make_float4(lu[t].x, lu[t].y, __int_as_float(nqu[t]), __int_as_float(myslot[t]));
         }
     __syncthreads();
 
@@ -1206,10 +1206,11 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         // exponent arguments are formed together with packed f32 arithmetic
         int ua = g0 * 16 + j, ub = ua + 16;
         // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
-        float2 la = make_float2(0.f, 0.f), lb = la;
-        int nqa = 0, nqb = 0;           // quads each of the lane's two units takes part in
-        if (ua < cnt) { la = lam[sorted[start + ua]]; nqa = nq_sorted[start + ua]; }
-        if (ub < cnt) { lb = lam[sorted[start + ub]]; nqb = nq_sorted[start + ub]; }
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+        if (ua < cnt) ra = urec[start + ua];
+        if (ub < cnt) rb = urec[start + ub];
+        const float2 la = make_float2(ra.x, ra.y), lb = make_float2(rb.x, rb.y);
+        const int nqa = __float_as_int(ra.z), nqb = __float_as_int(rb.z);      // quads each of the lane's two units takes part in
         const f32x2 nhi = {-la.x, -lb.x}, nlo = {-la.y, -lb.y};
         double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
         // The pass runs up to the quad count of its last unit in cutoff order (lane 15's second unit, or the
@@ -1330,8 +1331,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 // result rows of 16 floats (the spare columns hold zeros): one aligned 64-byte write per unit,
                 // wherever the cutoff order scattered the pass's units over the slots
                 constexpr int ROW = CPOL_N_COL;
-                if (u0 < cnt) psd_out[(long)sorted[start + u0] * ROW + j] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)sorted[start + u1] * ROW + j] = (float)db[r];
+                if (u0 < cnt) psd_out[(long)__float_as_int(urec[start + u0].w) * ROW + j] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)__float_as_int(urec[start + u1].w) * ROW + j] = (float)db[r];
             }
         }
     }
@@ -1341,17 +1342,17 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
 }
 
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
-                      const int *chunk_off, const int *chunk_bucket, int *sorted, unsigned char *nq_sorted, const float2 *lam,
+                      const int *chunk_off, const int *chunk_bucket, const int *sorted, float4 *urec, const float2 *lam,
                       float *psd_out, unsigned long long *work)
 {
     if (max_chunks <= 0) return;
     max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
     if (ct.ncol == 12)
         hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, nq_sorted, lam, psd_out, work);
+                           chunk_bucket, sorted, urec, lam, psd_out, work);
     else
         hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, nq_sorted, lam, psd_out, work);
+                           chunk_bucket, sorted, urec, lam, psd_out, work);
 }
 
 // =============================================================================
