@@ -38,7 +38,7 @@ def run_pass(counters, outdir):
         shutil.rmtree(outdir)
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-include-regex", KERNELS, "--output-format", "csv",
                                                "-d", outdir, "-o", "pmc", "--",
-                                               "python3", "bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+                                               "python3", "bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-host-copy"]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd=ROOT, env=env, check=True, timeout=240, stdout=subprocess.DEVNULL,
                    stderr=open(os.path.join(ROOT, "gpurun_out", "pmc_last.err"), "w"))
@@ -60,7 +60,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     result = {"command": "rocprofv3 --pmc <group> --kernel-include-regex \"%s\" -- python3 bench.py --steps 1 --warmup 1 "
-                         "--no-cpu-baseline" % KERNELS,
+                         "--no-cpu-baseline --no-host-copy" % KERNELS,
               "note": "one pass per counter group; values are averages per launch", "kernels": {}}
     for i, group in enumerate(PASSES):
         print("pass %d: %s" % (i, " ".join(group)), flush=True)
