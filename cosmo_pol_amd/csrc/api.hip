@@ -566,20 +566,16 @@ static void build_model_view(const cpol_ctx *ctx, ModelView &mv)
     mv.nz = ctx->nz; mv.ny = ctx->ny; mv.nx = ctx->nx; mv.nv = ctx->nv; mv.nvp = (ctx->nv + 3) & ~3;
     mv.llc0 = ctx->llc[0]; mv.llc1 = ctx->llc[1]; mv.res0 = ctx->res[0]; mv.res1 = ctx->res[1];
     mv.urc0 = ctx->urc[0]; mv.urc1 = ctx->urc[1];
-    for (int i = 0; i < ctx->nv; i++) mv.var_of_slot[i] = ctx->var_ids[i];
+    for (int v = 0; v < CPOL_V_COUNT; v++) mv.slot_of_var[v] = -1;
+    for (int i = 0; i < ctx->nv; i++) { mv.var_of_slot[i] = ctx->var_ids[i]; mv.slot_of_var[ctx->var_ids[i]] = i; }
 }
 
-// PSD set-up -> bucket sort -> integration -> per-ray reduction for nr rays whose
-// sub-beam profiles are already on the device.
-static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G, const float *vals, long plane,
-                       const float *elev, const signed char *mask, const double *wsub, const double *phi,
-                       float *obs, long obs_plane, long ray0, double *mask_out, double *rvel_out, double *spectrum)
+// Workspaces of run_physics for nu points.
+static int ensure_physics(cpol_ctx *ctx, const ClassTable &ct, long nu)
 {
-    const long nu = (long)nr * B * G;
     const int n_planes = ct.n_kinds * ct.n_cls;
     const long nslots = nu * n_planes;
     const int nb = n_planes * ct.ne_max * ct.nt_max;
-    const int nb_pol = ct.n_cls * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
     TRY(ensure(ctx, ctx->w->b_key, nslots * sizeof(cpol_key_t)));
     TRY(ensure(ctx, ctx->w->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_coef, nslots * sizeof(double)));
@@ -592,14 +588,42 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     TRY(ensure(ctx, ctx->w->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->w->b_vr, nu * sizeof(double)));
     if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->w->b_n0d, nslots * sizeof(double)));
+    return CPOL_OK;
+}
+
+// Clear the (bucket, shard) counters that the PSD set-up fills.
+static int clear_hist(cpol_ctx *ctx, const ClassTable &ct)
+{
+    const int nb = ct.n_kinds * ct.n_cls * ct.ne_max * ct.nt_max;
+    HIPCHK(ctx, hipMemsetAsync(ctx->w->b_hist.p, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
+    return CPOL_OK;
+}
+
+// PSD set-up -> bucket sort -> integration -> per-ray reduction for nr rays whose
+// sub-beam profiles are already on the device.  prepped: the PSD set-up has run already (k_front, after
+// ensure_physics and clear_hist), only Doppler scheme 1's radial velocity is still to be computed.
+static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G, const float *vals, long plane,
+                       const float *elev, const signed char *mask, const double *wsub, const double *phi,
+                       float *obs, long obs_plane, long ray0, double *mask_out, double *rvel_out, double *spectrum,
+                       bool prepped = false)
+{
+    const long nu = (long)nr * B * G;
+    const int n_planes = ct.n_kinds * ct.n_cls;
+    const long nslots = nu * n_planes;
+    const int nb = n_planes * ct.ne_max * ct.nt_max;
+    const int nb_pol = ct.n_cls * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
+    TRY(ensure_physics(ctx, ct, nu));
     int *hist = (int *)ctx->w->b_hist.p, *cursor = hist + CPOL_SORT_SHARDS * (nb + 1), *offs = cursor + CPOL_SORT_SHARDS * (nb + 1),
         *chunk_off = offs + (nb + 1);
     {
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
-    HIPCHK(ctx, hipMemsetAsync(hist, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
-    launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
-                (cpol_key_t *)ctx->w->b_key.p, (int *)ctx->w->b_rank.p, (float2 *)ctx->w->b_lam.p, (double *)ctx->w->b_coef.p,
-                (double *)ctx->w->b_n0d.p, hist, (double *)ctx->w->b_vr.p);
+    if (!prepped) {
+        TRY(clear_hist(ctx, ct));
+        launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
+                    (cpol_key_t *)ctx->w->b_key.p, (int *)ctx->w->b_rank.p, (float2 *)ctx->w->b_lam.p, (double *)ctx->w->b_coef.p,
+                    (double *)ctx->w->b_n0d.p, hist, (double *)ctx->w->b_vr.p);
+    } else if (ctx->cfg.doppler_scheme == 1)
+        launch_vr1(ctx->stream, ct, nu, G, vals, plane, elev, phi, (double *)ctx->w->b_vr.p);
     launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->w->b_cbkt.p);
     launch_scatter(ctx->stream, nu, ct.n_cls, (const cpol_key_t *)ctx->w->b_key.p, (const int *)ctx->w->b_rank.p, offs, cursor,
                    (int *)ctx->w->b_sorted.p);
@@ -730,14 +754,17 @@ static void geom_params(const cpol_ctx *ctx, GeomParams &gp)
     gp.refr_S = ctx->refr_tab; gp.refr_H = ctx->refr_tab + n; gp.refr_E = ctx->refr_tab + 2 * n;
 }
 
-static int ensure_geom(cpol_ctx *ctx, long nrb, long nu)
+// points_too: the per-point arrays that the stand-alone geometry kernel writes (k_front keeps them in registers)
+static int ensure_geom(cpol_ctx *ctx, long nrb, long nu, bool points_too = true)
 {
-    TRY(ensure(ctx, ctx->w->b_S, nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->w->b_H, nu * sizeof(float)));
+    if (points_too) {
+        TRY(ensure(ctx, ctx->w->b_S, nu * sizeof(float)));
+        TRY(ensure(ctx, ctx->w->b_H, nu * sizeof(float)));
+        TRY(ensure(ctx, ctx->w->b_lat, nu * sizeof(double)));
+        TRY(ensure(ctx, ctx->w->b_lon, nu * sizeof(double)));
+        TRY(ensure(ctx, ctx->w->b_coords, nu * 2 * sizeof(float)));
+    }
     TRY(ensure(ctx, ctx->w->b_E, nu * sizeof(float)));
-    TRY(ensure(ctx, ctx->w->b_lat, nu * sizeof(double)));
-    TRY(ensure(ctx, ctx->w->b_lon, nu * sizeof(double)));
-    TRY(ensure(ctx, ctx->w->b_coords, nu * 2 * sizeof(float)));
     TRY(ensure(ctx, ctx->w->b_line, (size_t)nrb * CPOL_LINE_N * sizeof(double)));
     TRY(ensure(ctx, ctx->w->b_phi, (size_t)nrb * 2 * sizeof(double)));
     return CPOL_OK;
@@ -821,7 +848,7 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
     if (rays_per_batch < 1) rays_per_batch = 1;
     if (rays_per_batch > n_rays || no_alloc) rays_per_batch = n_rays;
     long nu_max = (long)rays_per_batch * per_ray;
-    TRY(ensure_geom(ctx, (long)rays_per_batch * B, nu_max));
+    TRY(ensure_geom(ctx, (long)rays_per_batch * B, nu_max, false));
     TRY(ensure(ctx, w.b_vals, (size_t)CPOL_V_COUNT * nu_max * sizeof(float)));
     TRY(ensure(ctx, w.b_mask, nu_max));
     GeomParams gp;
@@ -829,6 +856,12 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
     ModelView mv;
     build_model_view(ctx, mv);
     const double *wsub = ctx->quad_dev + 2 * B;
+    // variables that Doppler scheme 1's k_vr1 reads back
+    unsigned vr1_mask = 1u << CPOL_V_RHO | 1u << CPOL_V_U | 1u << CPOL_V_V | 1u << CPOL_V_W;
+    for (int h = 0; h < ct.n_cls && ctx->cfg.doppler_scheme == 1; h++) {
+        vr1_mask |= 1u << ct.dop[h].q_var | 1u << ct.dop[h].t_var;
+        if (ct.dop[h].qn_var >= 0) vr1_mask |= 1u << ct.dop[h].qn_var;
+    }
     if (host && !ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     int prev_r0 = -1, prev_nr = 0, n_batch = 0;
     hipEvent_t prev_done = nullptr;
@@ -836,23 +869,29 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
         int nr = n_rays - r0 < rays_per_batch ? n_rays - r0 : rays_per_batch;
         long nu = (long)nr * per_ray;
         {
-            StageTimer t_(ctx, CPOL_ST_GEOM);
-            launch_geom(ctx->stream, gp, nr, az_dev + r0, el_dev + r0,
-                        ctx->quad_dev, (double *)w.b_line.p, (float *)w.b_S.p, (float *)w.b_H.p,
-                        (float *)w.b_E.p, (double *)w.b_lat.p, (double *)w.b_lon.p, (float *)w.b_coords.p,
-                        (double *)w.b_phi.p, mv, status + r0);
-            launch_gather_central(ctx->stream, nr, B, G, (const float *)w.b_S.p, (const float *)w.b_H.p,
-                                  (const double *)w.b_lat.p, (const double *)w.b_lon.p, out->dist,
-                                  out->height, out->lat, out->lon, r0);
-        }
-        {
+            // geometry of the points, interpolation and PSD set-up in one kernel; the variables that a later
+            // kernel reads are the only ones that reach memory
             StageTimer t_(ctx, CPOL_ST_INTERP);
-            launch_interp(ctx->stream, mv, nu, (const float *)w.b_coords.p, (const float *)w.b_H.p,
-                          (float *)w.b_vals.p, nu_max, (signed char *)w.b_mask.p, nullptr);
+            TRY(ensure_physics(ctx, ct, nu));
+            TRY(clear_hist(ctx, ct));
+            FrontOut fo;
+            memset(&fo, 0, sizeof(fo));
+            fo.E = (float *)w.b_E.p; fo.mask = (signed char *)w.b_mask.p;
+            fo.vals = (float *)w.b_vals.p; fo.plane = nu_max;
+            const int ds = ctx->cfg.doppler_scheme;
+            fo.write_mask = ds == 3 ? ~0u
+                          : ds == 2 ? (1u << CPOL_V_RHO | 1u << CPOL_V_U | 1u << CPOL_V_V | 1u << CPOL_V_W)
+                          : ds == 1 ? vr1_mask : 0u;
+            fo.dist = out->dist; fo.height = out->height; fo.lat = out->lat; fo.lon = out->lon;
+            fo.ray0 = r0; fo.status = status + r0;
+            fo.key = (cpol_key_t *)w.b_key.p; fo.rank = (int *)w.b_rank.p; fo.lam = (float2 *)w.b_lam.p;
+            fo.coef = (double *)w.b_coef.p; fo.n0d = (double *)w.b_n0d.p; fo.hist = (int *)w.b_hist.p;
+            launch_front(ctx->stream, gp, mv, ct, nr, az_dev + r0, el_dev + r0, ctx->quad_dev, (double *)w.b_line.p,
+                         (double *)w.b_phi.p, wsub, ds == 3 ? 0 : ds, fo);
         }
         TRY(run_physics(ctx, ct, nr, B, G, (const float *)w.b_vals.p, nu_max, (const float *)w.b_E.p,
                         (const signed char *)w.b_mask.p, wsub, (const double *)w.b_phi.p,
-                        out->obs, RG, r0, out->mask, out->rvel, out->dspectrum));
+                        out->obs, RG, r0, out->mask, out->rvel, out->dspectrum, true));
         if (host) {
             // this batch's kernels are queued: now hand the previous batch to the copy stream (a copy into
             // pageable memory blocks the host, which by then has given the GPU its next batch)

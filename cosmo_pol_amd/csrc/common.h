@@ -80,6 +80,7 @@ struct ModelView {
     float llc0, llc1, res0, res1;  // (Lo1, La1), (dlon, dlat)
     float urc0, urc1;
     int   var_of_slot[CPOL_MAX_VARS];   // uploaded variable i -> cpol_var slot
+    int   slot_of_var[CPOL_V_COUNT];    // the inverse, -1 for a variable that was not uploaded
 };
 
 struct GeomParams {
@@ -234,6 +235,23 @@ struct Dop2In {                    // inputs of the Doppler scheme-2 reduction i
     const float *xq[CPOL_MAX_CLASSES];
     int n_t[CPOL_MAX_CLASSES];
 };
+struct FrontOut {
+    float  *E;                 // [nu] elevation at the point
+    signed char *mask;         // [nu] interpolation code
+    float  *vals; long plane;  // variable planes, written for the variables in write_mask
+    unsigned write_mask;
+    float  *dist, *height;     // outputs of the central sub-beam (any may be NULL), rows of n_gates from ray0 on
+    double *lat, *lon;
+    long   ray0;
+    int    *status;            // per ray of the batch
+    cpol_key_t *key; int *rank; float2 *lam; double *coef; double *n0d; int *hist;
+};
+
+void launch_front(hipStream_t s, const GeomParams &gp, const ModelView &mv, const ClassTable &ct, int n_rays,
+                  const double *az, const double *el, const double *quad, double *line, double *phi,
+                  const double *wsub, int doppler, const FrontOut &fo);
+void launch_vr1(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
+                const float *elev, const double *phi_sc, double *vr);
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const cpol_key_t *key,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,

@@ -222,18 +222,17 @@ __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict_
     }
 }
 
-// One thread per (ray, sub-beam, gate).
-__global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict__ line,
-                           float *__restrict__ S_out, float *__restrict__ H_out, float *__restrict__ E_out,
-                           double *__restrict__ lat_out, double *__restrict__ lon_out, float *__restrict__ coords,
-                           ModelView mv, int *__restrict__ status)
-{
-    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_total) return;
-    int g = (int)(u % gp.n_gates);
-    long rb = u / gp.n_gates;
-    const double *L = line + rb * LINE_N;
+// Position of gate g on the geodesic line L of its (ray, sub-beam): ground distance, height and elevation of the
+// refraction model, geographic and rotated-pole coordinates.
+struct GeoPoint {
+    float  S, H, E;
+    double lat, lon;
+    float  rlat, rlon;
+    bool   outside;        // outside the model domain (interpolation.py:359-362)
+};
 
+__device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, const double *__restrict__ L, int g, GeoPoint &out)
+{
     float S, H, E;
     if (gp.n_refr > 0) {
         // ---- refraction table solved on the host (scheme 2, atm_refraction.py:45-84) ----
@@ -253,7 +252,7 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
         S = (float)Sd; H = (float)Hd;
         E = (float)Ed * (float)(180.0 / M_PI);
     }
-    S_out[u] = S; H_out[u] = H; E_out[u] = E;
+    out.S = S; out.H = H; out.E = E;
 
     // ---- geodesic position at distance S along the line ----
     const double f = 1.0 / 298.257223563, f1 = 1 - f;
@@ -286,7 +285,7 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     double lon12 = lam12 / DEG;
     double lon = ang_normalize(ang_normalize(gp.lon0) + ang_normalize(lon12));
     double lat = atan2d(sbet2, f1 * cbet2);
-    lat_out[u] = lat; lon_out[u] = lon;
+    out.lat = lat; out.lon = lon;
 
     // ---- rotated pole (north pole from the southern-pole metadata) ----
     double pollon = gp.pole_lon_s - 180.0;
@@ -301,13 +300,29 @@ __global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict
     double a1 = -sdl * cphi;
     double a2 = -sp * cphi * cdl + cp * sphi;
     double rlat = asin(a0) / DEG, rlon = atan2(a1, a2) / DEG;
-    coords[2 * u] = (float)rlat;
-    coords[2 * u + 1] = (float)rlon;
+    out.rlat = (float)rlat;
+    out.rlon = (float)rlon;
     // domain check of interpolation.py:359-362 (float64 coordinates against float32 corners)
-    if (rlon < (double)mv.llc0 || rlat < (double)mv.llc1 || rlon > (double)mv.urc0 || rlat > (double)mv.urc1) {
-        int r = (int)(rb / gp.n_sub);
-        status[r] = CPOL_ERR_DOMAIN;
-    }
+    out.outside = rlon < (double)mv.llc0 || rlat < (double)mv.llc1 || rlon > (double)mv.urc0 || rlat > (double)mv.urc1;
+}
+
+// One thread per (ray, sub-beam, gate).
+__global__ void k_geom_pts(GeomParams gp, long n_total, const double *__restrict__ line,
+                           float *__restrict__ S_out, float *__restrict__ H_out, float *__restrict__ E_out,
+                           double *__restrict__ lat_out, double *__restrict__ lon_out, float *__restrict__ coords,
+                           ModelView mv, int *__restrict__ status)
+{
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_total) return;
+    int g = (int)(u % gp.n_gates);
+    long rb = u / gp.n_gates;
+    GeoPoint p;
+    geom_point(gp, mv, line + rb * LINE_N, g, p);
+    S_out[u] = p.S; H_out[u] = p.H; E_out[u] = p.E;
+    lat_out[u] = p.lat; lon_out[u] = p.lon;
+    coords[2 * u] = p.rlat;
+    coords[2 * u + 1] = p.rlon;
+    if (p.outside) status[(int)(rb / gp.n_sub)] = CPOL_ERR_DOMAIN;
 }
 
 void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *az, const double *el,
@@ -362,9 +377,11 @@ __device__ inline int level_search(const float *__restrict__ col, int dim, float
 #define INTERP_XCD_RUN 72
 #define INTERP_REC 17
 #define INTERP_BATCH 4
-__global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords, const float *__restrict__ Hh,
-                         float *__restrict__ vals, long plane, signed char *__restrict__ mask,
-                         float *__restrict__ raw_out)
+// Interpolation of one point per thread by a workgroup of 256 threads; every thread of the workgroup calls it (it
+// synchronises).  Returns the point's code (0 inside the model, 1 below the terrain or off the grid, -1 above the
+// model top) and leaves the interpolated variable of slot v in s_rec[wave][lane][v].
+__device__ inline int interp_point(const ModelView &mv, float (*__restrict__ s_rec)[64][INTERP_REC], bool live, float H,
+                                   float rlat, float rlon)
 {
     // Phase A (one thread per point): grid position, terrain test, level search.
     // Phase B (wave-cooperative): the 2 x nvp values of a neighbour column are contiguous in memory, so
@@ -376,19 +393,9 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
     // Phase B overwrites words 0..nvp-1 of a point's record with its results once it has read the record (the
     // lanes of a wave run in lockstep and a record is read only in the iteration that owns it, the offsets at
     // the top of its group of four), so the results need no area of their own: 17 KB per workgroup.
-    __shared__ float s_rec[4][64][INTERP_REC];
-    // Workgroups are dealt to the eight XCDs in turn, each XCD with an L2 of its own.  Neighbouring sub-beams and
-    // rays read the same model columns, so an XCD takes runs of INTERP_XCD_RUN consecutive blocks (about four
-    // rays of nine sub-beams); short runs keep the XCDs evenly loaded although high elevations leave the model early.
-    const long kx = blockIdx.x >> 3;
-    const long bid = ((kx / INTERP_XCD_RUN) * 8 + (blockIdx.x & 7)) * INTERP_XCD_RUN + kx % INTERP_XCD_RUN;
-    long u = bid * blockDim.x + threadIdx.x;
-    const bool live = u < n;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const float qnan = __builtin_nanf("");
-    float H = live ? Hh[u] : 0.f;
-    float p0 = live ? (coords[2 * u] - mv.llc1) / mv.res1 : -1.f;       // lat-like -> row
-    float p1 = live ? (coords[2 * u + 1] - mv.llc0) / mv.res0 : -1.f;   // lon-like -> column
+    float p0 = live ? (rlat - mv.llc1) / mv.res1 : -1.f;       // lat-like -> row
+    float p1 = live ? (rlon - mv.llc0) / mv.res0 : -1.f;       // lon-like -> column
     int iy = (int)floorf(p0), ix = (int)floorf(p1);
     float x = fmodf(p0, 1.0f), y = fmodf(p1, 1.0f);
     float dx = 1.0f - x, dy = 1.0f - y;
@@ -515,7 +522,6 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
             }
         }
     }
-    if (mask && live) mask[u] = (signed char)code;
     float *rec = s_rec[wv][lane];
     rec[12] = x; rec[13] = y; rec[14] = __int_as_float(code);
 #pragma unroll
@@ -584,8 +590,31 @@ __global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords,
         }
     }
     __syncthreads();
+    return code;
+}
+
+// Workgroups are dealt to the eight XCDs in turn, each XCD with an L2 of its own.  Neighbouring sub-beams and
+// rays read the same model columns, so an XCD takes runs of INTERP_XCD_RUN consecutive blocks (about four
+// rays of nine sub-beams); short runs keep the XCDs evenly loaded although high elevations leave the model early.
+__device__ inline long interp_block_id()
+{
+    const long kx = blockIdx.x >> 3;
+    return ((kx / INTERP_XCD_RUN) * 8 + (blockIdx.x & 7)) * INTERP_XCD_RUN + kx % INTERP_XCD_RUN;
+}
+
+__global__ void k_interp(ModelView mv, long n, const float *__restrict__ coords, const float *__restrict__ Hh,
+                         float *__restrict__ vals, long plane, signed char *__restrict__ mask,
+                         float *__restrict__ raw_out)
+{
+    __shared__ float s_rec[4][64][INTERP_REC];
+    const long u = interp_block_id() * blockDim.x + threadIdx.x;
+    const bool live = u < n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float qnan = __builtin_nanf("");
+    const int code = interp_point(mv, s_rec, live, live ? Hh[u] : 0.f, live ? coords[2 * u] : 0.f, live ? coords[2 * u + 1] : 0.f);
+    if (mask && live) mask[u] = (signed char)code;
     if (live) {
-        for (int v = 0; v < nv; v++) {
+        for (int v = 0; v < mv.nv; v++) {
             float o = s_rec[wv][lane][v];
             // raw_out keeps the reference's sentinels; vals gets NaN (interpolation.py:277)
             if (raw_out) raw_out[(long)v * n + u] = code == 0 ? o : (code < 0 ? -9999.f : qnan);
@@ -830,28 +859,57 @@ __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
     *len = end - hl;
 }
 
-__global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
-                       const float *__restrict__ elev, const signed char *__restrict__ /*mask: invalid gates carry NaN*/,
-                       const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
-                       cpol_key_t *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
-                       double *__restrict__ coef, double *__restrict__ n0d, int *__restrict__ hist,
-                       double *__restrict__ vr)
+// Doppler scheme 1 for one point: closed-form PSD-weighted fall speed (doppler_sz.py:130-153) and projection on
+// the beam (:75-87).  rb = index of the point's (ray, sub-beam); the density correction refers to its first gate.
+__device__ inline double doppler1_radial(const ClassTable &ct, const float *__restrict__ vals, long plane, long uu, long rb,
+                                         int n_gates, float e_raw, const double *__restrict__ phi_sc)
 {
-    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int lane = threadIdx.x & 63;
-    bool live = u < nu;
-    long uu = live ? u : 0;
-    long rb = uu / n_gates;
-    int b = (int)(rb % n_sub);
-    float T = vals[(long)CPOL_V_T * plane + uu];
-    float e_raw = elev[uu];
-    float e = fold_elev(e_raw);
-    double w = wsub[b];
+    double vh = 0., nn = 0.;            // nansum_arr: NaN counts as 0 (utilities.py:46-66)
+    for (int h = 0; h < ct.n_cls; h++) {
+        const PsdView &p = ct.dop[h];
+        float q = vals[(long)p.q_var * plane + uu];
+        float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
+        // a negative mass density (extrapolation below the lowest level) still yields finite
+        // 2-moment parameters in the reference (clamped mean mass); the other branches give NaN
+        if (q > 0.f || (p.kind == 2 && q < 0.f)) {
+            double l, n0, vi, ni, ll;
+            float Tp = vals[(long)p.t_var * plane + uu];
+            psd_params(p, q, qn, Tp, &l, &n0, &ll);
+            vi = p.vel_factor * n0 * p.alpha / p.nu * exp(ll * (-(p.beta + p.mu + 1) / p.nu));
+            if (p.kind == 2) ni = (double)qn;
+            else ni = p.ntot_factor * n0 / p.nu * exp(ll * (-(p.mu + 1) / p.nu));
+            vh += (vi != vi ? 0. : vi);
+            nn += (ni != ni ? 0. : ni);
+        } else if (p.kind == 2 && qn == qn) {
+            nn += (double)qn;             // lambda is NaN, N_int = ntot = QN (hydrometeors.py:77-78)
+        }
+    }
+    float rho = vals[(long)CPOL_V_RHO * plane + uu];
+    float rho0 = vals[(long)CPOL_V_RHO * plane + rb * n_gates];
+    float rc = sqrtf(rho / rho0);
+    double vhyd = vh / nn * (double)rc;
+    float th = e_raw * (float)(M_PI / 180.0);
+    double sph = phi_sc[2 * rb], cph = phi_sc[2 * rb + 1];
+    double U = vals[(long)CPOL_V_U * plane + uu], V = vals[(long)CPOL_V_V * plane + uu];
+    double W = vals[(long)CPOL_V_W * plane + uu];
+    return (U * sph + V * cph) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
+}
+
+// PSD set-up of one point for every class: table node (bucket key), lambda, float64 coefficients, and the point's
+// position inside its (bucket, shard) counter.  val(v) returns the point's model variable v; the 64 lanes of a wave
+// hold 64 consecutive points.
+template <class ValFn>
+__device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool live, int lane, float T, float e_raw,
+                                    double w, int doppler, ValFn val, cpol_key_t *__restrict__ key,
+                                    int *__restrict__ rank, float2 *__restrict__ lam, double *__restrict__ coef,
+                                    double *__restrict__ n0d, int *__restrict__ hist)
+{
+    const float e = fold_elev(e_raw);
     for (int h = 0; h < ct.n_cls; h++) {
         const PsdView &p = ct.psd[h];
         const LutView &lv = ct.lut[h];
-        float q = vals[(long)p.q_var * plane + uu];
-        float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
+        float q = val(p.q_var);
+        float qn = p.qn_var >= 0 ? val(p.qn_var) : 0.f;
         bool valid = live && (q > 0.f);
         int k = -1;
         if (valid) {
@@ -883,9 +941,9 @@ __global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_g
             const PsdView &pd = ct.dop[h];
             const long dslot = (long)(ct.n_cls + h) * nu + u;
             if (valid) {
-                float qd = vals[(long)pd.q_var * plane + uu];
-                float qnd = pd.qn_var >= 0 ? vals[(long)pd.qn_var * plane + uu] : 0.f;
-                float Td = vals[(long)pd.t_var * plane + uu];
+                float qd = val(pd.q_var);
+                float qnd = pd.qn_var >= 0 ? val(pd.qn_var) : 0.f;
+                float Td = val(pd.t_var);
                 double l, n0;
                 psd_params(pd, qd, qnd, Td, &l, &n0);
                 if (qd == 0.f) l = __builtin_nan("");
@@ -898,38 +956,100 @@ __global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_g
             // k_scan_shards and k_scatter reuse the polarimetric counters, no second round of atomics
         }
     }
-    if (doppler == 1 && live) {
-        // doppler_sz.py:130-153 (closed-form PSD-weighted fall speed) and :75-87 (projection)
-        double vh = 0., nn = 0.;            // nansum_arr: NaN counts as 0 (utilities.py:46-66)
-        for (int h = 0; h < ct.n_cls; h++) {
-            const PsdView &p = ct.dop[h];
-            float q = vals[(long)p.q_var * plane + uu];
-            float qn = p.qn_var >= 0 ? vals[(long)p.qn_var * plane + uu] : 0.f;
-            // a negative mass density (extrapolation below the lowest level) still yields finite
-            // 2-moment parameters in the reference (clamped mean mass); the other branches give NaN
-            if (q > 0.f || (p.kind == 2 && q < 0.f)) {
-                double l, n0, vi, ni, ll;
-                float Tp = vals[(long)p.t_var * plane + uu];
-                psd_params(p, q, qn, Tp, &l, &n0, &ll);
-                vi = p.vel_factor * n0 * p.alpha / p.nu * exp(ll * (-(p.beta + p.mu + 1) / p.nu));
-                if (p.kind == 2) ni = (double)qn;
-                else ni = p.ntot_factor * n0 / p.nu * exp(ll * (-(p.mu + 1) / p.nu));
-                vh += (vi != vi ? 0. : vi);
-                nn += (ni != ni ? 0. : ni);
-            } else if (p.kind == 2 && qn == qn) {
-                nn += (double)qn;             // lambda is NaN, N_int = ntot = QN (hydrometeors.py:77-78)
-            }
+}
+
+__global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
+                       const float *__restrict__ elev, const signed char *__restrict__ /*mask: invalid gates carry NaN*/,
+                       const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
+                       cpol_key_t *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
+                       double *__restrict__ coef, double *__restrict__ n0d, int *__restrict__ hist,
+                       double *__restrict__ vr)
+{
+    long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int lane = threadIdx.x & 63;
+    bool live = u < nu;
+    long uu = live ? u : 0;
+    long rb = uu / n_gates;
+    int b = (int)(rb % n_sub);
+    float T = vals[(long)CPOL_V_T * plane + uu];
+    float e_raw = elev[uu];
+    prep_classes(ct, nu, u, live, lane, T, e_raw, wsub[b], doppler,
+                 [&](int v) { return vals[(long)v * plane + uu]; }, key, rank, lam, coef, n0d, hist);
+    if (doppler == 1 && live) vr[u] = doppler1_radial(ct, vals, plane, uu, rb, n_gates, e_raw, phi_sc);
+}
+
+// Doppler scheme 1 on its own, for callers whose PSD set-up ran inside another kernel.
+__global__ void k_vr1(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
+                      const float *__restrict__ elev, const double *__restrict__ phi_sc, double *__restrict__ vr)
+{
+    const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nu) return;
+    vr[u] = doppler1_radial(ct, vals, plane, u, u / n_gates, n_gates, elev[u], phi_sc);
+}
+
+// The per-point front of the hot path in one kernel: position of the point (geom_point), interpolation of the
+// model state (interp_point) and PSD set-up (prep_classes), the values passing from one to the next in registers
+// and LDS.  Only what a later kernel reads goes to memory: the elevation, the interpolation code, the variables
+// named in write_mask (bit v = model variable v), and the central sub-beam's position as the ray's outputs.
+__global__ __launch_bounds__(256, 4)
+void k_front(GeomParams gp, ModelView mv, ClassTable ct, long nu, const double *__restrict__ line,
+             const double *__restrict__ wsub, int doppler, FrontOut fo)
+{
+    __shared__ float s_rec[4][64][INTERP_REC];
+    const long u = interp_block_id() * blockDim.x + threadIdx.x;
+    if (u - threadIdx.x >= nu) return;          // a workgroup of the grid's padding
+    const bool live = u < nu;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long uu = live ? u : 0;
+    const int g = (int)(uu % gp.n_gates);
+    const long rb = uu / gp.n_gates;
+    const int b = (int)(rb % gp.n_sub);
+    GeoPoint p;
+    geom_point(gp, mv, line + rb * LINE_N, g, p);
+    if (live) {
+        fo.E[u] = p.E;
+        if (p.outside) fo.status[(int)(rb / gp.n_sub)] = CPOL_ERR_DOMAIN;
+        if (b == gp.n_sub / 2) {       // geometry of the central sub-beam (scattering_sz.py:154-157)
+            const long o = (fo.ray0 + rb / gp.n_sub) * (long)gp.n_gates + g;
+            if (fo.dist) fo.dist[o] = p.S;
+            if (fo.height) fo.height[o] = p.H;
+            if (fo.lat) fo.lat[o] = p.lat;
+            if (fo.lon) fo.lon[o] = p.lon;
         }
-        float rho = vals[(long)CPOL_V_RHO * plane + uu];
-        float rho0 = vals[(long)CPOL_V_RHO * plane + rb * n_gates];
-        float rc = sqrtf(rho / rho0);
-        double vhyd = vh / nn * (double)rc;
-        float th = e_raw * (float)(M_PI / 180.0);
-        double sph = phi_sc[2 * rb], cph = phi_sc[2 * rb + 1];
-        double U = vals[(long)CPOL_V_U * plane + uu], V = vals[(long)CPOL_V_V * plane + uu];
-        double W = vals[(long)CPOL_V_W * plane + uu];
-        vr[u] = (U * sph + V * cph) * (double)cosf(th) + (W - vhyd) * (double)sinf(th);
     }
+    const int code = interp_point(mv, s_rec, live, p.H, p.rlat, p.rlon);
+    const float qnan = __builtin_nanf("");
+    const float *rec = s_rec[wv][lane];
+    if (live) {
+        fo.mask[u] = (signed char)code;
+        for (int v = 0; v < mv.nv; v++) {
+            const int var = mv.var_of_slot[v];
+            if ((fo.write_mask >> var) & 1u) fo.vals[(long)var * fo.plane + u] = code == 0 ? rec[v] : qnan;
+        }
+    }
+    auto val = [&](int v) { return code == 0 ? rec[mv.slot_of_var[v]] : qnan; };
+    prep_classes(ct, nu, u, live, lane, val(CPOL_V_T), p.E, wsub[b], doppler, val, fo.key, fo.rank, fo.lam, fo.coef,
+                 fo.n0d, fo.hist);
+}
+
+void launch_front(hipStream_t s, const GeomParams &gp, const ModelView &mv, const ClassTable &ct, int n_rays,
+                  const double *az, const double *el, const double *quad, double *line, double *phi,
+                  const double *wsub, int doppler, const FrontOut &fo)
+{
+    const int nl = n_rays * gp.n_sub;
+    hipLaunchKernelGGL(k_geom_line, dim3((nl + 63) / 64), dim3(64), 0, s, gp, n_rays, az, el, quad, line, phi, fo.status);
+    const long nu = (long)nl * gp.n_gates;
+    const long nb = (nu + 255) / 256;
+    const long per = 8L * INTERP_XCD_RUN;
+    hipLaunchKernelGGL(k_front, dim3((unsigned)((nb + per - 1) / per * per)), dim3(256), 0, s, gp, mv, ct, nu, line, wsub,
+                       doppler, fo);
+}
+
+void launch_vr1(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
+                const float *elev, const double *phi_sc, double *vr)
+{
+    hipLaunchKernelGGL(k_vr1, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, ct, nu, n_gates, vals, plane, elev,
+                       phi_sc, vr);
 }
 
 __global__ void k_sincos_deg(int n, const double *__restrict__ deg, double *__restrict__ sc)
