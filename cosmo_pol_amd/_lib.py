@@ -56,7 +56,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_model_range_certified', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_run_rays_static', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -86,6 +86,7 @@ def load():
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_term_cutoff.argtypes = [vp, C.c_int]
     lib.cpol_get_term_cutoff.argtypes = [vp, c_float_p]
+    lib.cpol_model_range_certified.argtypes = [vp]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
                                       c_float_p, c_float_p, c_float_p, c_double_p]
@@ -194,6 +195,14 @@ class Context(object):
         e = (C.c_float * 4)()
         self._check(self.lib.cpol_get_term_cutoff(self.h, e), 'cpol_get_term_cutoff')
         return {k: float(e[i]) for k, i in CLASS_INDEX.items() if e[i] > 0}
+
+    def model_range_certified(self):
+        """True when the uploaded model's values let the vertical interpolation share one reciprocal per level pair
+        (bit-identical to the division inside the certified range), False when every quotient is a full division."""
+        rc = self.lib.cpol_model_range_certified(self.h)
+        if rc < 0:
+            self._check(rc, 'cpol_model_range_certified')
+        return bool(rc)
 
     def set_batch_units(self, n):
         self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')

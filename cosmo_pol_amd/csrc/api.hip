@@ -150,6 +150,13 @@ extern "C" int cpol_set_term_cutoff(cpol_ctx *ctx, int certified)
     return CPOL_OK;
 }
 
+extern "C" int cpol_model_range_certified(cpol_ctx *ctx)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    if (!ctx->have_model) return fail(ctx, CPOL_ERR_STATE, "no model uploaded");
+    return ctx->fast_div ? 1 : 0;
+}
+
 extern "C" int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES])
 {
     if (!ctx || !exponent) return CPOL_ERR_ARG;
@@ -315,6 +322,18 @@ extern "C" int cpol_upload_model(cpol_ctx *ctx, int nvars, const int *var_ids, c
         launch_transpose_levels(ctx->stream, stage, ctx->dcol, nz, ncell, nvp, i);
         ctx->var_ids[i] = var_ids[i];
     }
+    {   // does every division of the vertical interpolation stay in the range of the shared-reciprocal form?
+        unsigned *flag = nullptr, bad = 1;
+        HIPCHK(ctx, hipMalloc((void **)&flag, sizeof(unsigned)));
+        HIPCHK(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream));
+        launch_model_range(ctx->stream, ctx->dcol, nvox * nvp, ctx->zcol, nz, nvox, flag);
+        const hipError_t e = hipMemcpyAsync(&bad, flag, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(flag);
+        HIPCHK(ctx, e);
+        HIPCHK(ctx, e2);
+        ctx->fast_div = bad == 0;
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->nz = nz; ctx->ny = ny; ctx->nx = nx; ctx->nv = nvars;
@@ -332,6 +351,9 @@ static void fill_psd(PsdView &v, const cpol_psd &p)
     v.n0_unit = pow(1000., -(1 + p.mu));
     v.lam_unit = pow(1000., -p.nu);
     v.log_lam_unit = log(v.lam_unit);
+    v.c_exp = p.psd_kind == 0 ? 1. / (4. + p.mu) : p.psd_kind == 1 ? 1. / (p.b + 1) : -p.nu / p.b;
+    v.c_n = p.nu / p.ntot_factor;
+    v.c_n_exp = (p.mu + 1) / p.nu;
 }
 
 extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,
@@ -566,6 +588,7 @@ static void build_model_view(const cpol_ctx *ctx, ModelView &mv)
     mv.nz = ctx->nz; mv.ny = ctx->ny; mv.nx = ctx->nx; mv.nv = ctx->nv; mv.nvp = (ctx->nv + 3) & ~3;
     mv.llc0 = ctx->llc[0]; mv.llc1 = ctx->llc[1]; mv.res0 = ctx->res[0]; mv.res1 = ctx->res[1];
     mv.urc0 = ctx->urc[0]; mv.urc1 = ctx->urc[1];
+    mv.fast_div = ctx->fast_div ? 1 : 0;
     for (int v = 0; v < CPOL_V_COUNT; v++) mv.slot_of_var[v] = -1;
     for (int i = 0; i < ctx->nv; i++) { mv.var_of_slot[i] = ctx->var_ids[i]; mv.slot_of_var[ctx->var_ids[i]] = i; }
 }

@@ -50,6 +50,9 @@ struct PsdView {
     int    q_var, qn_var, t_var;
     double n0_unit, lam_unit;      // 1000^-(1+mu), 1000^-nu (hydrometeors.py:149,151)
     double log_lam_unit;
+    // quotients of the constants above, worked out once on the host with the same float64 operations:
+    double c_exp;                  // exponent of lambda: 1 / (4 + mu) | 1 / (b + 1) | -nu / b  (kind 0 | 1 | 2)
+    double c_n, c_n_exp;           // kind 2: nu / ntot_factor, (mu + 1) / nu
 };
 
 struct ClassTable {
@@ -81,6 +84,7 @@ struct ModelView {
     float urc0, urc1;
     int   var_of_slot[CPOL_MAX_VARS];   // uploaded variable i -> cpol_var slot
     int   slot_of_var[CPOL_V_COUNT];    // the inverse, -1 for a variable that was not uploaded
+    int   fast_div;                     // the model's values allow the shared-reciprocal division (k_model_range)
 };
 
 struct GeomParams {
@@ -116,6 +120,7 @@ struct cpol_ctx {
     float *zcol = nullptr, *dcol = nullptr, *zc8 = nullptr;
     int nz = 0, ny = 0, nx = 0, nv = 0;
     int var_ids[CPOL_MAX_VARS];
+    bool fast_div = false;             // see ModelView::fast_div
     float llc[2], urc[2], res[2];
     double pole[2];
     LutDev lut[CPOL_MAX_CLASSES];
@@ -247,6 +252,7 @@ struct FrontOut {
     cpol_key_t *key; int *rank; float2 *lam; double *coef; double *n0d; int *hist;
 };
 
+void launch_model_range(hipStream_t s, const float *dcol, size_t n_val, const float *zcol, int nz, size_t n_z, unsigned *flag);
 void launch_front(hipStream_t s, const GeomParams &gp, const ModelView &mv, const ClassTable &ct, int n_rays,
                   const double *az, const double *el, const double *quad, double *line, double *phi,
                   const double *wsub, int doppler, const FrontOut &fo);

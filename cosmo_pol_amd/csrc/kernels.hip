@@ -7,6 +7,7 @@
 #include <math.h>
 
 #define DEG (M_PI / 180.0)
+#define RAD2DEG (180.0 / M_PI)
 
 // =============================================================================
 // model upload: [nz][ncell] -> [ncell][nz] with an output stride (variable interleave)
@@ -75,8 +76,41 @@ __device__ inline double ang_round(double x)
 
 __device__ inline double ang_normalize(double x)
 {
+    if (fabs(x) < 180.) return x;          // remainder(x, 360) is x itself there
     x = remainder(x, 360.0);
     return x != -180 ? x : 180;
+}
+
+// sin, cos, asin and atan of a small argument by their Taylor series: below SMALL_ANGLE the first term left out is
+// under 2^-55 of the result, so the value is the correctly rounded one up to the last bit, as with the
+// library routine, without its range reduction.  Every gate of a ground radar (150 km against the earth's radius)
+// takes this path; a larger argument goes to the library.
+#define SMALL_ANGLE 0.04
+__device__ inline void sincos_small(double x, double *s, double *c)
+{
+    if (fabs(x) < SMALL_ANGLE) {
+        const double x2 = x * x;
+        *s = x * (1. + x2 * (-1. / 6. + x2 * (1. / 120. + x2 * (-1. / 5040. + x2 * (1. / 362880. - x2 * (1. / 39916800.))))));
+        *c = 1. + x2 * (-0.5 + x2 * (1. / 24. + x2 * (-1. / 720. + x2 * (1. / 40320. - x2 * (1. / 3628800.)))));
+    } else sincos(x, s, c);
+}
+
+__device__ inline double asin_small(double x)
+{
+    if (fabs(x) < SMALL_ANGLE) {
+        const double x2 = x * x;
+        return x * (1. + x2 * (1. / 6. + x2 * (3. / 40. + x2 * (15. / 336. + x2 * (105. / 3456. + x2 * (945. / 42240.))))));
+    }
+    return asin(x);
+}
+
+__device__ inline double atan_small(double x)
+{
+    if (fabs(x) < SMALL_ANGLE) {
+        const double x2 = x * x;
+        return x * (1. + x2 * (-1. / 3. + x2 * (1. / 5. + x2 * (-1. / 7. + x2 * (1. / 9. + x2 * (-1. / 11. + x2 * (1. / 13.)))))));
+    }
+    return atan(x);
 }
 
 __device__ inline void sincosd(double x, double *sx, double *cx)
@@ -99,7 +133,7 @@ __device__ inline double atan2d(double y, double x)
     int q = 0;
     if (fabs(y) > fabs(x)) { double t = x; x = y; y = t; q = 2; }
     if (x < 0) { x = -x; ++q; }
-    double ang = atan2(y, x) / DEG;
+    double ang = atan2(y, x) * RAD2DEG;
     switch (q) {
     case 1: ang = (y >= 0 ? 180 : -180) - ang; break;
     case 2: ang = 90 - ang; break;
@@ -204,6 +238,8 @@ __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict_
     for (int l = 1; l <= 6; ++l) L[12 + l] = C1pa[l];
     for (int l = 1; l <= 5; ++l) L[18 + l] = C3a[l];
     L[24] = el_b;
+    L[30] = 1. / (6378137.0 * f1 * (1 + A1m1));
+    L[31] = ang_normalize(gp.lon0);
     {   // per-line trigonometry of k_geom_pts: elevation of the 4/3 model, rotated-pole latitude
         const double ela = el_b * M_PI / 180.;
         L[26] = sin(ela); L[27] = cos(ela);
@@ -247,8 +283,8 @@ __device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, con
         const double ke = 4. / 3.;
         double keR = ke * gp.earth_radius;
         double Hd = sqrt(rr * rr + keR * keR + 2 * rr * ke * gp.earth_radius * sel) - keR + gp.alt;
-        double Sd = keR * asin((rr * cel) / (keR + Hd));
-        double Ed = ela + atan(rr * cel / (rr * sel + keR + gp.alt));
+        double Sd = keR * asin_small((rr * cel) / (keR + Hd));
+        double Ed = ela + atan_small(rr * cel / (rr * sel + keR + gp.alt));
         S = (float)Sd; H = (float)Hd;
         E = (float)Ed * (float)(180.0 / M_PI);
     }
@@ -256,16 +292,15 @@ __device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, con
 
     // ---- geodesic position at distance S along the line ----
     const double f = 1.0 / 298.257223563, f1 = 1 - f;
-    const double bsemi = 6378137.0 * f1;
     const double tiny = 1.4916681462400413e-154;
     double salp0 = L[0], calp0 = L[1], ssig1 = L[2], csig1 = L[3], somg1 = L[4], comg1 = L[5];
-    double A1m1 = L[7], B11 = L[8], stau1 = L[9], ctau1 = L[10], A3c = L[11], B31 = L[12];
+    double B11 = L[8], stau1 = L[9], ctau1 = L[10], A3c = L[11], B31 = L[12];
     double C1pa[7], C3a[6];
     for (int l = 1; l <= 6; ++l) C1pa[l] = L[12 + l];
     for (int l = 1; l <= 5; ++l) C3a[l] = L[18 + l];
-    double tau12 = (double)S / (bsemi * (1 + A1m1));
+    double tau12 = (double)S * L[30];                    // S / (b (1 + A1 - 1))
     double s, c;
-    sincos(tau12, &s, &c);
+    sincos_small(tau12, &s, &c);
     double B12 = -sin_cos_series(stau1 * c + ctau1 * s, ctau1 * c - stau1 * s, C1pa, 6);
     double sig12 = tau12 - (B12 - B11);
     // sin / cos of sig12 = tau12 + dlt from those of tau12: |dlt| < 3e-3 (series terms of order f), so five
@@ -277,13 +312,14 @@ __device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, con
     double ssig2 = ssig1 * csig12 + csig1 * ssig12;
     double csig2 = csig1 * csig12 - ssig1 * ssig12;
     double sbet2 = calp0 * ssig2;
-    double cbet2 = hypot(salp0, calp0 * csig2);
+    const double cc2 = calp0 * csig2;
+    double cbet2 = sqrt(salp0 * salp0 + cc2 * cc2);      // operands of order one: no scaling needed
     if (cbet2 == 0) cbet2 = csig2 = tiny;
     double somg2 = salp0 * ssig2, comg2 = csig2;
     double omg12 = atan2(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);
     double lam12 = omg12 + A3c * (sig12 + (sin_cos_series(ssig2, csig2, C3a, 5) - B31));
-    double lon12 = lam12 / DEG;
-    double lon = ang_normalize(ang_normalize(gp.lon0) + ang_normalize(lon12));
+    double lon12 = lam12 * RAD2DEG;
+    double lon = ang_normalize(L[31] + ang_normalize(lon12));      // L[31]: the radar's longitude, normalised
     double lat = atan2d(sbet2, f1 * cbet2);
     out.lat = lat; out.lon = lon;
 
@@ -293,13 +329,14 @@ __device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, con
     double sp = L[28], cp = L[29];
     double dl = (lon - pollon) * DEG;
     // lat = atan2(sbet2, f1 cbet2): its sine and cosine are that pair normalised
-    const double hphi = hypot(sbet2, f1 * cbet2);
-    double sphi = sbet2 / hphi, cphi = f1 * cbet2 / hphi, sdl, cdl;
+    const double fc2 = f1 * cbet2;
+    const double rh = 1. / sqrt(sbet2 * sbet2 + fc2 * fc2);
+    double sphi = sbet2 * rh, cphi = fc2 * rh, sdl, cdl;
     sincos(dl, &sdl, &cdl);
     double a0 = cp * cphi * cdl + sp * sphi;
     double a1 = -sdl * cphi;
     double a2 = -sp * cphi * cdl + cp * sphi;
-    double rlat = asin(a0) / DEG, rlon = atan2(a1, a2) / DEG;
+    double rlat = asin(a0) * RAD2DEG, rlon = atan2(a1, a2) * RAD2DEG;
     out.rlat = (float)rlat;
     out.rlon = (float)rlon;
     // domain check of interpolation.py:359-362 (float64 coordinates against float32 corners)
@@ -372,6 +409,50 @@ __device__ inline int level_search(const float *__restrict__ col, int dim, float
         else return high;          // NaN height: the reference would not terminate
     }
     return high;
+}
+
+// The correctly rounded float32 quotient n / d from r, the refined reciprocal of d: the instruction sequence the
+// compiler emits for a float32 division, without its scaling of the operands and its handling of special values
+// - it returns the same bits wherever neither acts: d and n / d normal numbers, n zero or at least 2^-102, the
+// exponents of n and d less than 96 apart, everything finite.  k_model_range certifies an uploaded model for that.
+__device__ inline float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, r0, 1.f);
+    return fmaf(e, r0, r0);
+}
+__device__ inline float div_refined(float n, float d, float r)
+{
+    float q = n * r;
+    float e = fmaf(-d, q, n);
+    q = fmaf(e, r, q);
+    e = fmaf(-d, q, n);
+    return fmaf(e, r, q);
+}
+
+// Sets *flag when the model leaves the range in which div_refined is the division: a variable that is not zero,
+// finite and within [2^-78, 2^85] in magnitude (the difference of two such values is zero or at least 2^-101), or
+// a level thickness outside [2^-10, 2^14] m.
+__global__ void k_model_range(const float *__restrict__ dcol, size_t n_val, const float *__restrict__ zcol, int nz,
+                              size_t n_z, unsigned *__restrict__ flag)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_val; i += stride) {
+        const float a = fabsf(dcol[i]);
+        bad = bad || !(a == 0.f || (a >= 0x1p-78f && a <= 0x1p85f));
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_z; i += stride) {
+        if ((int)(i % nz) == nz - 1) continue;
+        const float d = fabsf(zcol[i] - zcol[i + 1]);
+        bad = bad || !(d >= 0x1p-10f && d <= 0x1p14f);
+    }
+    if (bad) *flag = 1u;
+}
+
+void launch_model_range(hipStream_t s, const float *dcol, size_t n_val, const float *zcol, int nz, size_t n_z, unsigned *flag)
+{
+    hipLaunchKernelGGL(k_model_range, dim3(2048), dim3(256), 0, s, dcol, n_val, zcol, nz, n_z, flag);
 }
 
 #define INTERP_XCD_RUN 72
@@ -572,9 +653,11 @@ __device__ inline int interp_point(const ModelView &mv, float (*__restrict__ s_r
                 const float f = j == 0 ? pdx * pdy : j == 1 ? pdx : j == 2 ? px : px * py;
                 const float g = j == 1 ? py : j == 2 ? pdy : 1.0f;
                 float o[4];
+                const float rd = mv.fast_div ? refined_rcp(d) : 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const float w = B[c] - (B[c] - A[c]) / d * hz;     // vertical interpolation (:151)
+                    const float nn = B[c] - A[c];
+                    const float w = B[c] - (mv.fast_div ? div_refined(nn, d, rd) : nn / d) * hz;     // vertical interpolation (:151)
                     const float t = (f * w) * g;
                     // lanes of column 0 collect ((t0 + t2) + t1) + t3: columns 2, 1, 3 sit 8, 4, 12 lanes up
                     const int s2 = __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, t), 0x201f);
@@ -812,21 +895,21 @@ __device__ inline bool psd_params(const PsdView &p, float q, float qn, float T, 
 {
     double ll;                       // natural log of *lam: later powers of lambda reuse it
     if (p.kind == 0) {
-        ll = log(p.lambda_factor / (double)q) * (1. / (4. + p.mu));
+        ll = log(p.lambda_factor / (double)q) * p.c_exp;
         *lam = exp(ll);
         *n0 = p.n0_fixed;
     } else if (p.kind == 1) {
         // exp through float64 so that subnormal float32 results are kept, as glibc's expf keeps them
         float n0f = 13.5f * (565000.0f * (float)exp((double)(-0.107f * (T - 273.15f)))) / 1000.f;
         float an0 = (float)p.a * n0f;
-        ll = log((double)an0 * p.lambda_factor / (double)q) * (1. / (p.b + 1));
+        ll = log((double)an0 * p.lambda_factor / (double)q) * p.c_exp;
         *lam = exp(ll);
         *n0 = (double)n0f;
     } else {
         float xm = q * 1.0f / (qn + 1.1920929e-07f);
         xm = fminf(fmaxf(xm, (float)p.x_min), (float)p.x_max);
-        double l0 = log(p.lambda_factor * (double)xm) * (-p.nu / p.b);
-        double n = (p.nu / p.ntot_factor) * (double)qn * exp(l0 * ((p.mu + 1) / p.nu));
+        double l0 = log(p.lambda_factor * (double)xm) * p.c_exp;
+        double n = p.c_n * (double)qn * exp(l0 * p.c_n_exp);
         *n0 = n * p.n0_unit;
         *lam = exp(l0) * p.lam_unit;
         ll = l0 + p.log_lam_unit;

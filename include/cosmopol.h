@@ -133,6 +133,13 @@ int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *do
  * (150 = exact zeros only, 0 = no table uploaded).  No counterpart in the reference. */
 int cpol_set_term_cutoff(cpol_ctx *ctx, int certified);
 int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES]);
+
+/* 1 when the uploaded model lets the vertical interpolation (interpolation_c.c:151, four float32 divisions per
+ * point, column and variable) share one refined reciprocal per level pair - the same bits as the division as long
+ * as every variable is zero or finite with a magnitude in [2^-78, 2^85] and every level is 2^-10 .. 2^14 m thick,
+ * which cpol_upload_model checks on the device; 0 when a value lies outside and every quotient is a full division;
+ * negative when no model has been uploaded.  No counterpart in the reference: a diagnostic of this library. */
+int cpol_model_range_certified(cpol_ctx *ctx);
 /* Upper bound of (ray x sub-beam x gate) positions processed per internal batch; bounds the
  * workspace the library allocates (default 32 Mi positions, about 26 GB with 2-moment input and Doppler scheme 2,
  * allocated only as far as a call needs it; at most 128 Mi). */

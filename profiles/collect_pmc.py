@@ -19,7 +19,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = "k_integrate|k_interp|k_prep|k_gate_reduce|k_geom_pts"
+KERNELS = "k_integrate|k_front|k_interp|k_prep|k_gate_reduce|k_geom_pts"
 PASSES = [
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM",
      "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_LDS"],

@@ -451,6 +451,52 @@ def test_interp_points_bit_exact():
         np.testing.assert_array_equal(out[i][ok].view(np.int32), want[ok].view(np.int32))
 
 
+@pytest.mark.parametrize('case', ['in_range', 'wide', 'tiny', 'nonfinite', 'thin_level'])
+def test_interp_division_forms(case):
+    """interpolation_c.c:151 divides by the level thickness once per variable.  Inside the range that
+    cpol_upload_model certifies the kernel shares one refined reciprocal per level pair; outside it every quotient
+    is a full division.  Either way the bits are the C restatement's: variables spread over the certified range's
+    40 decades, values below it (down to subnormals), non-finite values, a level one float32 step thick."""
+    m = small_model(scheme=1)
+    rng = np.random.default_rng(5)
+    fields = {k: np.array(v, dtype='float32') for k, v in m['fields'].items()}
+    zlev = np.array(m['zlev'], dtype='float32')
+    want_certified = True
+    if case == 'wide':
+        for k, e in (('U', 24.), ('V', -22.), ('QR_v', -15.), ('T', 20.)):
+            fields[k] = (fields[k] * np.float32(10.) ** rng.uniform(e - 1, e, fields[k].shape).astype('float32')).astype('float32')
+        assert 0 < np.abs(fields['V'][fields['V'] != 0]).min() and np.abs(fields['V'][fields['V'] != 0]).min() > 2. ** -78
+    elif case == 'tiny':
+        fields['QR_v'] = (fields['QR_v'] * np.float32(10.) ** rng.uniform(-36, -18, fields['QR_v'].shape).astype('float32')).astype('float32')
+        assert (np.abs(fields['QR_v'][fields['QR_v'] != 0]) < 2. ** -126).any()         # subnormals among them
+        want_certified = False
+    elif case == 'nonfinite':
+        fields['W'][3, 7, 9] = np.inf
+        fields['QS_v'][5, 11, 13] = np.nan
+        want_certified = False
+    elif case == 'thin_level':
+        zlev[4] = np.nextafter(zlev[5], np.float32(np.inf))          # one float32 step: 2.4e-4 or 4.9e-4 m
+        want_certified = False
+    conf = O.make_config(microphysics={'scheme': 1})
+    eng = engine.Engine(conf, device=0)
+    eng.upload_model(fields, zlev, m['proj_info'], m['resolution'])
+    assert eng.ctx.model_range_certified() == want_certified
+    n = 20000
+    coords = np.empty((n, 2), dtype='float32')
+    coords[:, 0] = -0.8 + 0.04 * rng.uniform(0, 38.99, n)
+    coords[:, 1] = -1.0 + 0.05 * rng.uniform(0, 46.99, n)
+    H = rng.uniform(100., 9500., n).astype('float32')
+    out = eng.ctx.interp_points(coords, H)
+    llc = np.array([-1.0, -0.8], dtype='float32')
+    res = np.array([0.05, 0.04], dtype='float32')
+    with np.errstate(all='ignore'):
+        for i, name in enumerate(fields.keys()):
+            want = O.interp_c(coords, H, fields[name], zlev, llc, res)
+            np.testing.assert_array_equal(np.isnan(out[i]), np.isnan(want), err_msg=name)
+            ok = ~np.isnan(want)
+            np.testing.assert_array_equal(out[i][ok].view(np.int32), want[ok].view(np.int32), err_msg=name)
+
+
 @pytest.mark.parametrize('nz', [3, 4, 7, 8, 9, 15, 33, 64, 80, 113])
 def test_interp_level_search_any_level_count(nz):
     """The level search starts from eight coarse heights at levels k (nz - 1) / 7 and narrows four ways at a
