@@ -455,6 +455,9 @@ void launch_model_range(hipStream_t s, const float *dcol, size_t n_val, const fl
     hipLaunchKernelGGL(k_model_range, dim3(2048), dim3(256), 0, s, dcol, n_val, zcol, nz, n_z, flag);
 }
 
+#ifndef FRONT_OCC
+#define FRONT_OCC 6
+#endif
 #define INTERP_XCD_RUN 72
 #define INTERP_REC 17
 #define INTERP_BATCH 4
@@ -1074,7 +1077,7 @@ __global__ void k_vr1(ClassTable ct, long nu, int n_gates, const float *__restri
 // model state (interp_point) and PSD set-up (prep_classes), the values passing from one to the next in registers
 // and LDS.  Only what a later kernel reads goes to memory: the elevation, the interpolation code, the variables
 // named in write_mask (bit v = model variable v), and the central sub-beam's position as the ray's outputs.
-__global__ __launch_bounds__(256, 4)
+__global__ __launch_bounds__(256, FRONT_OCC)
 void k_front(GeomParams gp, ModelView mv, ClassTable ct, long nu, const double *__restrict__ line,
              const double *__restrict__ wsub, int doppler, FrontOut fo)
 {
@@ -2078,6 +2081,7 @@ void launch_build_rcs(hipStream_t s, const float *raw, float *rcs, long n)
 // (3) the GH-weighted bin values are accumulated in float64.  Three classes (rain, snow,
 // graupel), as the reference's get_refl hard-wires.
 // =============================================================================
+#define SPEC_EDGE_TILE 512       // bins per pass of the edge table: 513 edges x 3 floats fit the 8 KB term area
 __global__ __launch_bounds__(64, 3)
 void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float *__restrict__ vals, long plane,
                 const float *__restrict__ elev, const signed char *__restrict__ mask, const double *__restrict__ wsub,
@@ -2093,20 +2097,23 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
     double *bs = acc + sp.n_vel;             // [n_vel] one sub-beam's weighted spectrum (turbulence broadening only)
     // per velocity bin: diameter index range [ia, ib) per class, float accumulator of the bin's reflectivity
     struct BinRec { short ia[3], ib[3]; float refl; };
+    struct SpecSub { double hor, sth, Ww, sig; float lam32[3], n032[3], rinv; int node[3]; int active; };
     BinRec *rec = (BinRec *)(acc + sp.n_vel * (sp.turb ? 2 : 1));
     const int lane = threadIdx.x;
     const int G = sp.n_gates, B = sp.n_sub, NV = sp.n_vel;
     const int r = blockIdx.x / G, g = blockIdx.x % G;
     for (int i = lane; i < NV; i += 64) acc[i] = 0.;
-    __syncthreads();
-    for (int b = 0; b < B; b++) {
+    // What a sub-beam needs before its bins: PSD parameters, table nodes, fall-speed conversion, turbulence width.
+    // One lane per sub-beam works these out side by side; the loop over the sub-beams then reads them from LDS.
+    SpecSub *subs = (SpecSub *)(rec + NV);
+    for (int b = lane; b < B; b += 64) {
         const long rb = (long)r * B + b;
         const long u = rb * G + g;
-        if (mask[u] != 0) continue;                       // wave-uniform (doppler_sz.py:271)
+        SpecSub ss;
+        ss.active = mask[u] == 0;                         // doppler_sz.py:271
         const float T = vals[(long)CPOL_V_T * plane + u];
         const float e_raw = elev[u];
         const float e_lut = fold_elev(e_raw);
-        float lam32[3], n032[3];
         for (int jc = 0; jc < 3; jc++) {
             const PsdView &p = ct.dop[jc];
             float q = vals[(long)p.q_var * plane + u];
@@ -2114,66 +2121,107 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
             double l, n0;
             psd_params(p, q, 0.f, Tp, &l, &n0);
             if (q == 0.f) l = __builtin_nan("");
-            lam32[jc] = (float)l; n032[jc] = (float)n0;
+            ss.lam32[jc] = (float)l; ss.n032[jc] = (float)n0;
+            // table node nearest to (elevation, temperature)
+            const LutView &lv = ct.lut[jc];
+            ss.node[jc] = nearest_node(e_lut, lv.e_min, lv.e_step, lv.n_e) * lv.n_t + nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
         }
         // fall speed at the velocity bins (doppler_sz.py:337-346), NumPy promotion kept
         const float rho = vals[(long)CPOL_V_RHO * plane + u], rho0 = vals[(long)CPOL_V_RHO * plane + rb * G];
-        const float rinv = 1.0f / sqrtf(rho / rho0);
+        ss.rinv = 1.0f / sqrtf(rho / rho0);
         const float th = e_raw * (float)(M_PI / 180.0);
         const double Uw = vals[(long)CPOL_V_U * plane + u], Vw = vals[(long)CPOL_V_V * plane + u];
-        const double Ww = vals[(long)CPOL_V_W * plane + u];
+        ss.Ww = vals[(long)CPOL_V_W * plane + u];
         // float32 sin/tan as the correctly rounded value: v/sin(theta) cancels against the wind term to a few
         // m/s out of hundreds at low elevation, so the last bit of these two decides which table term falls in
         // which velocity bin; the reference's result there depends on its libm in the same way
-        const double hor = (Uw * phi_sc[2 * rb] + Vw * phi_sc[2 * rb + 1]) / (double)(float)tan((double)th);
-        const double sth = (double)(float)sin((double)th);
+        ss.hor = (Uw * phi_sc[2 * rb] + Vw * phi_sc[2 * rb + 1]) / (double)(float)tan((double)th);
+        ss.sth = (double)(float)sin((double)th);
+        ss.sig = 0.;
+        if (sp.turb) {
+            // Standard deviation of the turbulence spread after Doviak and Zrnic (get_turb_std, doppler_sz.py:308-321,
+            // with true division), in velocity bins
+            const double edr = (double)vals[(long)CPOL_V_EDR * plane + u];
+            const double rng = sp.range_res * ((double)g + 0.5);
+            const double rt = rng * sp.sigma_theta;
+            double tstd;
+            if (sp.sigma_r < 0.1 * rt) tstd = cbrt((rng * edr * sp.sigma_theta * sp.kolm_a * sqrt(sp.kolm_a)) / 0.72);
+            else {
+                const double a135 = 1.35 * sp.kolm_a, ratio = rt / sp.sigma_r;
+                const double den = 11. / 15. + 4. / 15. * ratio * ratio;
+                tstd = cbrt((edr * sp.sigma_r * a135 * sqrt(a135)) * (den * sqrt(den)));      // x / den^(-3/2)
+            }
+            ss.sig = tstd / (varray[2] - varray[1]);
+        }
+        subs[b] = ss;
+    }
+    __syncthreads();
+    for (int b = 0; b < B; b++) {
+        const SpecSub &ss = subs[b];
+        if (!ss.active) continue;                         // wave-uniform
+        float lam32[3], n032[3];
+        for (int jc = 0; jc < 3; jc++) { lam32[jc] = ss.lam32[jc]; n032[jc] = ss.n032[jc]; }
+        const float rinv = ss.rinv;
+        const double Ww = ss.Ww, hor = ss.hor, sth = ss.sth;
         const double w = wsub[b];
-        // diameter interval of every velocity bin and class
-        for (int i = lane; i < NV; i += 64) {
-            BinRec br;
-            for (int jc = 0; jc < 3; jc++) { br.ia[jc] = -1; br.ib[jc] = -1; }      // -1: the class adds nothing to this bin
-            br.refl = 0.f;
-            if (i < NV - 1) {
-                double wh0 = (double)rinv * (Ww + hor - varray[i] / sth);
-                double wh1 = (double)rinv * (Ww + hor - varray[i + 1] / sth);
-                if (wh0 >= 0 && wh1 >= 0) {
-                    float Da[3], Db[3];
-                    bool keep = false;
-                    for (int jc = 0; jc < 3; jc++) {
-                        // (v / alpha)^(1 / beta) through exp(y log x): the float32 rounding hides its 1e-15
-                        float d0 = (float)powxy(sp.inv_alpha[jc] * wh0, sp.inv_beta[jc]);
-                        float d1 = (float)powxy(sp.inv_alpha[jc] * wh1, sp.inv_beta[jc]);
-                        // the reference clips the whole matrix with each later class's limits (:355-357)
-                        for (int jl = jc; jl < 3; jl++) {
-                            if (d0 >= sp.d_max[jl]) d0 = sp.d_max[jl];
-                            if (d0 <= sp.d_min[jl]) d0 = sp.d_min[jl];
-                            if (d1 >= sp.d_max[jl]) d1 = sp.d_max[jl];
-                            if (d1 <= sp.d_min[jl]) d1 = sp.d_min[jl];
-                        }
-                        Da[jc] = fminf(d0, d1); Db[jc] = fmaxf(d0, d1);
-                        keep = keep || (Db[jc] - Da[jc]) != 0.0f;
+        // Diameter interval of every velocity bin and class.  An edge of the velocity axis belongs to two bins: its
+        // three diameters (v / alpha)^(1 / beta), clipped, are worked out once per edge into the term area (free until
+        // the first class's terms), SPEC_EDGE_TILE bins at a time, and the bins read their two edges from there.
+        float *edge = (float *)term;                          // [tile + 1][3], NaN: negative fall speed at this edge
+        for (int i0 = 0; i0 < NV; i0 += SPEC_EDGE_TILE) {
+            const int n_e = min(SPEC_EDGE_TILE + 1, NV - i0);             // edges i0 .. i0 + n_e - 1
+            __syncthreads();
+            for (int e = lane; e < n_e; e += 64) {
+                const double wh = (double)rinv * (Ww + hor - varray[i0 + e] / sth);
+                float d[3];
+                for (int jc = 0; jc < 3; jc++) {
+                    // (v / alpha)^(1 / beta): an exact square or fourth power where 1 / beta is 2 or 4, else through
+                    // exp(y log x) - the float32 rounding hides its 1e-15
+                    const double x = sp.inv_alpha[jc] * wh;
+                    float dd = sp.inv_beta[jc] == 2. ? (float)(x * x)
+                             : sp.inv_beta[jc] == 4. ? (float)((x * x) * (x * x)) : (float)powxy(x, sp.inv_beta[jc]);
+                    // the reference clips the whole matrix with each later class's limits (:355-357)
+                    for (int jl = jc; jl < 3; jl++) {
+                        if (dd >= sp.d_max[jl]) dd = sp.d_max[jl];
+                        if (dd <= sp.d_min[jl]) dd = sp.d_min[jl];
                     }
-                    if (keep) {
+                    d[jc] = wh >= 0 ? dd : __builtin_nanf("");
+                }
+                edge[3 * e] = d[0]; edge[3 * e + 1] = d[1]; edge[3 * e + 2] = d[2];
+            }
+            __syncthreads();
+            for (int i = i0 + lane; i < min(i0 + SPEC_EDGE_TILE, NV); i += 64) {
+                BinRec br;
+                for (int jc = 0; jc < 3; jc++) { br.ia[jc] = -1; br.ib[jc] = -1; }      // -1: the class adds nothing to this bin
+                br.refl = 0.f;
+                if (i < NV - 1) {
+                    const float *e0 = edge + 3 * (i - i0), *e1 = e0 + 3;
+                    if (e0[0] == e0[0] && e1[0] == e1[0]) {         // both fall speeds are >= 0
+                        float Da[3], Db[3];
+                        bool keep = false;
                         for (int jc = 0; jc < 3; jc++) {
-                            if (lam32[jc] > 0.f) {
-                                int ia = (int)((Da[jc] - sp.d_min[jc]) / sp.step[jc]);
-                                int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
-                                br.ia[jc] = (short)min(max(ia, 0), 1024);
-                                br.ib[jc] = (short)min(max(ib, 0), 1024);
+                            Da[jc] = fminf(e0[jc], e1[jc]); Db[jc] = fmaxf(e0[jc], e1[jc]);
+                            keep = keep || (Db[jc] - Da[jc]) != 0.0f;
+                        }
+                        if (keep) {
+                            for (int jc = 0; jc < 3; jc++) {
+                                if (lam32[jc] > 0.f) {
+                                    int ia = (int)((Da[jc] - sp.d_min[jc]) / sp.step[jc]);
+                                    int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
+                                    br.ia[jc] = (short)min(max(ia, 0), 1024);
+                                    br.ib[jc] = (short)min(max(ib, 0), 1024);
+                                }
                             }
                         }
                     }
                 }
+                rec[i] = br;
             }
-            rec[i] = br;
         }
         for (int jc = 0; jc < 3; jc++) {
             if (!(lam32[jc] > 0.f)) continue;                 // wave-uniform: the class adds nothing (doppler_c.c:20)
-            // terms of the class at the table node nearest to (elevation, temperature)
-            const LutView &lv = ct.lut[jc];
-            int ie = nearest_node(e_lut, lv.e_min, lv.e_step, lv.n_e);
-            int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
-            const float *sl = rcs_tab[jc] + (long)(ie * lv.n_t + it) * 1024;
+            // terms of the class at the sub-beam's table node
+            const float *sl = rcs_tab[jc] + (long)ss.node[jc] * 1024;
             const double lamd = (double)lam32[jc];
             const float muj = sp.mu[jc];
             __syncthreads();                                  // the previous class's sums have read term[]
@@ -2206,11 +2254,22 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
             }
             __syncthreads();
             // the reference's float accumulator per bin (doppler_c.c:24-26), classes in order
+            // Eight terms are fetched ahead of the eight dependent additions that use them: the chain then runs at
+            // the latency of its own convert-add-convert, not at that of an LDS read per term.
             for (int i = lane; i < NV - 1; i += 64) {
                 const int ia = rec[i].ia[jc], ib = rec[i].ib[jc];
                 if (ia >= 0) {
                     float sum = 0.f;
-                    for (int k = ia; k < ib; k++) sum = (float)((double)sum + term[k]);
+                    for (int k = ia; k < ib; k += 8) {
+                        double t[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) t[j] = term[min(k + j, 1023)];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const float s2 = (float)((double)sum + t[j]);
+                            sum = k + j < ib ? s2 : sum;
+                        }
+                    }
                     rec[i].refl += sum * sp.step[jc] * n032[jc];
                 }
             }
@@ -2223,21 +2282,10 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
         }
         __syncthreads();
         if (sp.turb) {
-            // Spectrum spread by turbulence (doppler_sz.py:94-96).  Standard deviation after Doviak and Zrnic
-            // (get_turb_std, :308-321, with true division), in velocity bins; then gaussian_filter1d of the bins
-            // (reflecting edges, radius int(4 sigma + 0.5), normalised weights) and rescaling to the power the
-            // sub-beam's spectrum had before (turb_spectrum_spread, :323-335).
-            const double edr = (double)vals[(long)CPOL_V_EDR * plane + u];
-            const double rng = sp.range_res * ((double)g + 0.5);
-            const double rt = rng * sp.sigma_theta;
-            double tstd;
-            if (sp.sigma_r < 0.1 * rt) tstd = cbrt((rng * edr * sp.sigma_theta * sp.kolm_a * sqrt(sp.kolm_a)) / 0.72);
-            else {
-                const double a135 = 1.35 * sp.kolm_a, ratio = rt / sp.sigma_r;
-                const double den = 11. / 15. + 4. / 15. * ratio * ratio;
-                tstd = cbrt((edr * sp.sigma_r * a135 * sqrt(a135)) * (den * sqrt(den)));      // x / den^(-3/2)
-            }
-            const double sig = tstd / (varray[2] - varray[1]);
+            // Spectrum spread by turbulence (doppler_sz.py:94-96): gaussian_filter1d of the bins (reflecting edges,
+            // radius int(4 sigma + 0.5), normalised weights) and rescaling to the power the sub-beam's spectrum
+            // had before (turb_spectrum_spread, :323-335).
+            const double sig = ss.sig;
             if (!(sig > 1e-15)) {                 // no spread (scipy skips such an axis); NaN falls here as well
                 for (int i = lane; i < NV; i += 64) acc[i] += bs[i];
             } else {
@@ -2291,7 +2339,8 @@ void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, 
                      const double *varray, const float *const *raw, const float *const *d_axis, double *spectrum,
                      double *rvel, long ray0)
 {
-    size_t lds = (size_t)((sp.turb ? 3 * 1024 : 1024) + sp.n_vel * (sp.turb ? 2 : 1)) * sizeof(double) + (size_t)sp.n_vel * 16;
+    size_t lds = (size_t)((sp.turb ? 3 * 1024 : 1024) + sp.n_vel * (sp.turb ? 2 : 1)) * sizeof(double) + (size_t)sp.n_vel * 16
+               + (size_t)sp.n_sub * 80;          // terms, accumulators, BinRec per bin, SpecSub per sub-beam
     hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((long)n_rays * sp.n_gates)), dim3(64), lds, s, ct, sp, nu, vals, plane,
                        elev, mask, wsub, phi_sc, varray, raw, d_axis, spectrum, rvel, ray0);
 }
