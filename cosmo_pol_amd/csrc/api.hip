@@ -91,8 +91,9 @@ extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     timing_collect(ctx);
-    if (on && !ctx->work_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->work_dev, 128 * sizeof(unsigned long long)));
-    if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, 128 * sizeof(unsigned long long)));
+    const size_t work_bytes = 2 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE * sizeof(unsigned long long);
+    if (on && !ctx->work_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->work_dev, work_bytes));
+    if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, work_bytes));
     ctx->timing = on != 0;
     for (int i = 0; i < CPOL_N_STAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_launches[i] = 0; }
     ctx->valid_units = 0; ctx->dop_units = 0;
@@ -123,10 +124,13 @@ extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters,
     if (!ctx->work_dev) return CPOL_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long w[128];
-    HIPCHK(ctx, hipMemcpy(w, ctx->work_dev, sizeof(w), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> w(2 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE);
+    HIPCHK(ctx, hipMemcpy(w.data(), ctx->work_dev, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     double tot = 0., totd = 0.;
-    for (int i = 0; i < 64; i++) { tot += (double)w[i]; totd += (double)w[64 + i]; }
+    for (int i = 0; i < CPOL_WORK_SLOTS; i++) {
+        tot += (double)w[(size_t)i * CPOL_WORK_STRIDE];
+        totd += (double)w[(size_t)(CPOL_WORK_SLOTS + i) * CPOL_WORK_STRIDE];
+    }
     *evaluated_unit_diameters = 16. * tot;
     if (doppler_unit_diameters) *doppler_unit_diameters = 16. * totd;
     return CPOL_OK;

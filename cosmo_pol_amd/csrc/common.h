@@ -12,6 +12,10 @@ typedef short cpol_key_t;         // bucket (class, elevation node, temperature 
 #define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_LINE_N 32            // doubles per (ray, sub-beam) record of the geodesic line constants
+// work counters of the two integration kernels: CPOL_WORK_SLOTS each, one per 64-byte line, so that the wavefronts
+// of a launch spread their atomics over many lines
+#define CPOL_WORK_SLOTS 1024
+#define CPOL_WORK_STRIDE 8
 #define CPOL_N_COL 16             // MFMA N dimension: 12 scattering components + 4 spare columns
 
 struct LutDev {

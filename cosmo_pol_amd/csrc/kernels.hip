@@ -1543,7 +1543,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         }
     }
     if (work) {                                       // wave-uniform count of evaluated unit x quad steps
-        if (lane == 0) atomicAdd(&work[(blockIdx.x * NW + wave) & 63], (unsigned long long)wsum);
+        if (lane == 0) atomicAdd(&work[((blockIdx.x * NW + wave) & (CPOL_WORK_SLOTS - 1)) * CPOL_WORK_STRIDE], (unsigned long long)wsum);
     }
 }
 
@@ -1599,8 +1599,9 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 {
     __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
     __shared__ int s_hist[68];
-    __shared__ unsigned short s_perm[CPOL_CHUNK_UNITS];
-    __shared__ unsigned char s_nq[CPOL_CHUNK_UNITS];
+    // the chunk's units in cutoff order: slope (hi, lo), slot, quad count - the integration reads its units from
+    // here, not through the index list again
+    __shared__ float4 s_u[CPOL_CHUNK_UNITS];
     const int c_lo = chunk_off[b_lo];
     const unsigned total = (unsigned)(chunk_off[b_hi] - c_lo);
     // runs of INTEG_XCD_RUN consecutive chunks go round the XCDs, as in k_integrate
@@ -1635,16 +1636,28 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     // where its N(D) becomes an exact float32 zero.  A wavefront stops at the last quad any of its 128 units
     // needs. ----
     const bool cut_ok = ct.dop_cut_ok[h];
-    int nqu[2], myrank[2];
+    int nqu[2], myrank[2], sl_[2];
+    float2 lt_[2];
+    double n0_[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {          // index, then slope and N0 side by side, for both units before any use
+        const int i = tid + t * DOP_THREADS;
+        sl_[t] = i < cnt ? sorted[start + i] + (int)slot0 : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = tid + t * DOP_THREADS;
+        lt_[t] = i < cnt ? lam[sl_[t]] : make_float2(0.f, 0.f);
+        n0_[t] = i < cnt ? n0d[sl_[t]] : 0.;
+    }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int i = tid + t * DOP_THREADS;
         nqu[t] = 64; myrank[t] = 0;
         if (i < cnt) {
-            const int sl = sorted[start + i] + (int)slot0;
-            if (n0d[sl] == 0.) nqu[t] = 0;
+            if (n0_[t] == 0.) nqu[t] = 0;
             else if (cut_ok) {
-                const float2 lt = lam[sl];
+                const float2 lt = lt_[t];
                 const float xc = psd_cutoff_x(lt.x + lt.y);
                 int c = 0;
 #pragma unroll
@@ -1668,7 +1681,8 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int i = tid + t * DOP_THREADS;
-        if (i < cnt) { const int pos = s_hist[nqu[t]] + myrank[t]; s_perm[pos] = (unsigned short)i; s_nq[pos] = (unsigned char)nqu[t]; }
+        if (i < cnt)
+            s_u[s_hist[nqu[t]] + myrank[t]] = make_float4(lt_[t].x, lt_[t].y, __int_as_float(sl_[t]), __int_as_float(nqu[t]));
     }
     __syncthreads();
     // a wavefront takes 128 consecutive positions of that order, a lane positions p and p + 64 of them
@@ -1676,14 +1690,17 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     const int pos[2] = {wbase + lane, wbase + 64 + lane};
     const bool have[2] = {pos[0] < cnt, pos[1] < cnt};
     if (wbase >= cnt) return;
-    const int nq8 = (s_nq[min(wbase + 127, cnt - 1)] + 7) & ~7;
-    if (work && lane == 0) atomicAdd(&work[64 + (blockIdx.x & 63)], (unsigned long long)nq8 * (unsigned)min(cnt - wbase, 128));
+    const int nq8 = __builtin_amdgcn_readfirstlane((__float_as_int(s_u[min(wbase + 127, cnt - 1)].w) + 7) & ~7);
+    if (work && lane == 0)
+        atomicAdd(&work[(CPOL_WORK_SLOTS + ((blockIdx.x * (DOP_THREADS / 64) + (tid >> 6)) & (CPOL_WORK_SLOTS - 1))) * CPOL_WORK_STRIDE],
+                  (unsigned long long)nq8 * (unsigned)min(cnt - wbase, 128));
     int slot[2];
     float2 l[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-        slot[t] = have[t] ? sorted[start + s_perm[pos[t]]] + (int)slot0 : 0;
-        l[t] = have[t] ? lam[slot[t]] : make_float2(0.f, 0.f);
+        const float4 ur = have[t] ? s_u[pos[t]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        slot[t] = __float_as_int(ur.z);
+        l[t] = make_float2(ur.x, ur.y);
     }
     if (nq8 == 0) {          // nothing to integrate for any unit of the wavefront
 #pragma unroll
@@ -1691,7 +1708,14 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
             if (have[t]) dop_out[(long)slot[t] - slot0] = make_float2(0.f, 0.f);
         return;
     }
-    const f32x4 *BB4 = (const f32x4 *)(lds + 1024);      // word j of quad q: the moment pairs of diameters 16 q + 2 j, + 1
+    // The image words of a quad are the same for every lane of the wavefront: they are read from the image in memory
+    // as wave-uniform scalar loads (constant address space) into scalar registers, not as 64 copies through LDS; LDS
+    // keeps its copy of the node for the bisection above.
+    typedef const __attribute__((address_space(4))) f32x4 cf4_t;
+    typedef const __attribute__((address_space(4))) float cf1_t;
+    const float *node_img = lv.table + (long)(ie * lv.n_t + it) * CPOL_DOP_SLICE;
+    cf1_t *GX = (cf1_t *)(unsigned long long)node_img;
+    cf4_t *BB4 = (cf4_t *)(unsigned long long)(node_img + 1024);      // word j of quad q: the moment pairs of diameters 16 q + 2 j, + 1
     double s12[2] = {0., 0.}, s13[2] = {0., 0.};
     const float gstep = ct.dop_geo_step[h];      // diameter step when N(D) is geometric, else 0
     if (gstep > 0.f) {
@@ -1711,13 +1735,13 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
             f32x2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int q4 = 0; q4 < 8; q4 += 4) {
-                const float xs0 = lds[16 * (qo + q4)];
+                const float xs0 = GX[16 * (qo + q4)];
                 float nq_[2];
 #pragma unroll
                 for (int t = 0; t < 2; t++) nq_[t] = __builtin_amdgcn_exp2f(__builtin_fmaf(-l[t].x, xs0, -l[t].y * xs0));
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const f32x4 *w = BB4 + 8 * (qo + q4 + m);
+                    cf4_t *w = BB4 + 8 * (qo + q4 + m);
                     f32x2 S[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                     for (int j = 7; j >= 0; j--) {
