@@ -277,8 +277,8 @@ def launch_ranks(n, argv):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20, help='timed volumes (a volume takes about 9 ms; the first one or two after a pause run slower)')
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
                     help='strong (default): the rays of ONE volume are shared out over the ranks and gathered on rank 0; '
                          'weak: every rank simulates a whole volume of its own')
