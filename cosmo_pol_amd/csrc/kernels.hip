@@ -1321,6 +1321,10 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     if (tid < 256) ((float4 *)(lds + LDS_X))[tid] = ((const float4 *)lv.xq)[tid];
     if (tid < 16) ((float4 *)(lds + LDS_ZERO))[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 68) s_hist[tid] = 0;
+    // the first D^nu of every quad once more, next to each other: the bisection below reads them at whatever index
+    // each lane has reached, and 16 floats apart those reads would share four LDS banks
+    float *s_xq = lds + 128;
+    if (tid >= 64 && tid < 128) s_xq[tid - 64] = lv.xq[(tid - 64) * 16];
     int myslot[UPT];
     float2 lu[UPT];
 #pragma unroll
@@ -1341,7 +1345,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             int c = 0;
 #pragma unroll
             for (int step = 64; step >= 1; step >>= 1)
-                if (c + step <= 64 && lds[LDS_X + (c + step - 1) * 16] <= xc) c += step;
+                if (c + step <= 64 && s_xq[c + step - 1] <= xc) c += step;
             nqu[t] = c;
         }
         if (tid + t * INTEG_THREADS < cnt) myrank[t] = atomicAdd(&s_hist[nqu[t]], 1);
@@ -1599,6 +1603,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
 {
     __shared__ __attribute__((aligned(16))) float lds[CPOL_DOP_SLICE];
     __shared__ int s_hist[68];
+    __shared__ float s_xq[64];           // first D^nu - D_0^nu of every quad, next to each other for the bisection
     // the chunk's units in cutoff order: slope (hi, lo), slot, quad count - the integration reads its units from
     // here, not through the index list again
     __shared__ float4 s_u[CPOL_CHUNK_UNITS];
@@ -1629,6 +1634,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         for (int i = tid; i < CPOL_DOP_SLICE / 4; i += DOP_THREADS) dst[i] = src[i];
     }
     if (tid < 68) s_hist[tid] = 0;
+    if (tid >= 64 && tid < 128) s_xq[tid - 64] = (lv.table + (long)(ie * lv.n_t + it) * CPOL_DOP_SLICE)[(tid - 64) * 16];
     __syncthreads();
     // ---- order the chunk's units by how many quads of 16 diameters they need (as k_integrate does): none for
     // a unit whose N0 is an exact zero (its moments are multiplied by it: the 1-moment snow intercept fed
@@ -1662,7 +1668,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
                 int c = 0;
 #pragma unroll
                 for (int step = 64; step >= 1; step >>= 1)
-                    if (c + step <= 64 && lds[16 * (c + step - 1)] <= xc) c += step;     // first D^nu - D_0^nu of a quad
+                    if (c + step <= 64 && s_xq[c + step - 1] <= xc) c += step;
                 nqu[t] = c;
             }
             myrank[t] = atomicAdd(&s_hist[nqu[t]], 1);
