@@ -110,6 +110,9 @@ int  cpol_synchronize(cpol_ctx *ctx);
  * quantity its arithmetic scales with; doppler_units = units of the Doppler scheme-2
  * moments that were integrated separately because their PSD differs (stage INTEGRATE_DOP;
  * 0 when the moments ride on the polarimetric units). */
+/* cpol_run_rays* works the per-position front (geometry of the points, interpolation, PSD set-up) in one kernel and
+ * books it under INTERP, the scans and the scatter of the bucket sort under PREP_SORT; GEOM and the PSD set-up share
+ * of PREP_SORT are filled by cpol_geolocate / cpol_run_profiles, which run those parts on their own. */
 #define CPOL_N_STAGES 7
 enum cpol_stage { CPOL_ST_GEOM = 0, CPOL_ST_INTERP, CPOL_ST_PREP_SORT, CPOL_ST_INTEGRATE, CPOL_ST_OBSERVABLES,
                   CPOL_ST_INTEGRATE_DOP, CPOL_ST_SPECTRUM /* Doppler spectrum, doppler_scheme 3 */ };
