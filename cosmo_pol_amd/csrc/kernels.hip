@@ -2261,17 +2261,24 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                 // instead of sixteen.  The axis values are float32 roundings of the ideal ones; the difference
                 // delta enters to first order, exp(-lambda (D + delta)) = exp(-lambda D) (1 - lambda delta), the
                 // second order being below 1e-10 for |lambda delta| < 1e-5.
-                const double D0 = (double)d_axis[jc][0] + (double)lane * sp.geo_step[jc];
+                const float *dx = d_axis[jc];
+                const double D0 = (double)dx[0] + (double)lane * sp.geo_step[jc];
                 double E = exp(-lamd * D0);
                 const double R = exp(-lamd * 64. * sp.geo_step[jc]);
-                for (int i = 0; i < 16; i++) {
-                    const int k = lane + 64 * i;
-                    const float rcs = sl[k];
-                    const double D = (double)d_axis[jc][k];
-                    const double delta = D - (D0 + (double)(64 * i) * sp.geo_step[jc]);
-                    const double dm = muj == 0.f ? 1. : (muj == 1.f ? D : (muj == 0.5f ? sqrt(D) : pow(D, (double)muj)));
-                    term[k] = dm * (E - E * (lamd * delta)) * (double)rcs;
-                    E *= R;
+                // eight diameters' table values are fetched before the eight terms that use them
+                for (int i0 = 0; i0 < 16; i0 += 8) {
+                    float rc[8], da[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { rc[j] = sl[lane + 64 * (i0 + j)]; da[j] = dx[lane + 64 * (i0 + j)]; }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int i = i0 + j, k = lane + 64 * i;
+                        const double D = (double)da[j];
+                        const double delta = D - (D0 + (double)(64 * i) * sp.geo_step[jc]);
+                        const double dm = muj == 0.f ? 1. : (muj == 1.f ? D : (muj == 0.5f ? sqrt(D) : pow(D, (double)muj)));
+                        term[k] = dm * (E - E * (lamd * delta)) * (double)rc[j];
+                        E *= R;
+                    }
                 }
             } else {
                 for (int k = lane; k < 1024; k += 64) {
