@@ -2111,6 +2111,9 @@ void launch_build_rcs(hipStream_t s, const float *raw, float *rcs, long n)
 // (3) the GH-weighted bin values are accumulated in float64.  Three classes (rain, snow,
 // graupel), as the reference's get_refl hard-wires.
 // =============================================================================
+#ifndef SPEC_LONG_BIN
+#define SPEC_LONG_BIN 256       // bins from this length on have their chains cut where the terms stop mattering
+#endif
 #define SPEC_EDGE_TILE 512       // bins per pass of the edge table: 513 edges x 3 floats fit the 8 KB term area
 __global__ __launch_bounds__(64, 3)
 void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float *__restrict__ vals, long plane,
@@ -2136,6 +2139,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
     // What a sub-beam needs before its bins: PSD parameters, table nodes, fall-speed conversion, turbulence width.
     // One lane per sub-beam works these out side by side; the loop over the sub-beams then reads them from LDS.
     SpecSub *subs = (SpecSub *)(rec + NV);
+    float *suf = (float *)(subs + B);        // [129] largest |term| from each block of eight diameters on, 0 past the axis
     for (int b = lane; b < B; b += 64) {
         const long rb = (long)r * B + b;
         const long u = rb * G + g;
@@ -2198,6 +2202,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
         // three diameters (v / alpha)^(1 / beta), clipped, are worked out once per edge into the term area (free until
         // the first class's terms), SPEC_EDGE_TILE bins at a time, and the bins read their two edges from there.
         float *edge = (float *)term;                          // [tile + 1][3], NaN: negative fall speed at this edge
+        bool has_long[3] = {false, false, false};             // a bin of the class takes SPEC_LONG_BIN diameters or more
         for (int i0 = 0; i0 < NV; i0 += SPEC_EDGE_TILE) {
             const int n_e = min(SPEC_EDGE_TILE + 1, NV - i0);             // edges i0 .. i0 + n_e - 1
             __syncthreads();
@@ -2240,6 +2245,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                                     int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
                                     br.ia[jc] = (short)min(max(ia, 0), 1024);
                                     br.ib[jc] = (short)min(max(ib, 0), 1024);
+                                    has_long[jc] = has_long[jc] || br.ib[jc] - br.ia[jc] >= SPEC_LONG_BIN;
                                 }
                             }
                         }
@@ -2290,6 +2296,35 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                 }
             }
             __syncthreads();
+            // Where the chain may stop: a term below 2^-26 of the float sum leaves it as it is (the sum's half step is at
+            // least that, on either side, and a tie keeps the even sum), so once every term still to come is below
+            // 2^-27 of the sum the rest of the bin changes nothing.  suf[m] = largest |term| of the diameters 8 m ..
+            // 1023, rounded up; a NaN term counts as infinite (it must reach the sum).  Worked out only when a bin of the
+            // class is long enough for it to pay.
+            const bool long_bin = __any(has_long[jc]);
+            if (long_bin) {
+                float v[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    double a = 0.;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const double t = term[8 * (lane + 64 * h2) + j];
+                        a = t != t ? (double)__builtin_inff() : fmax(a, fabs(t));
+                    }
+                    v[h2] = (float)a * 1.000001f;
+                }
+                // suffix maxima over the 64 lanes of each half, then the upper half's total into the lower
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float o0 = __shfl_down(v[0], off), o1 = __shfl_down(v[1], off);
+                    if (lane + off < 64) { v[0] = fmaxf(v[0], o0); v[1] = fmaxf(v[1], o1); }
+                }
+                v[0] = fmaxf(v[0], __shfl(v[1], 0));
+                suf[lane] = v[0]; suf[lane + 64] = v[1];
+                if (lane == 0) suf[128] = 0.f;
+                __syncthreads();
+            }
             // the reference's float accumulator per bin (doppler_c.c:24-26), classes in order
             // Eight terms are fetched ahead of the eight dependent additions that use them: the chain then runs at
             // the latency of its own convert-add-convert, not at that of an LDS read per term.
@@ -2298,6 +2333,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                 if (ia >= 0) {
                     float sum = 0.f;
                     for (int k = ia; k < ib; k += 8) {
+                        if (long_bin && suf[k >> 3] < fabsf(sum) * 0x1p-27f) break;      // nothing from here on changes the sum
                         double t[8];
 #pragma unroll
                         for (int j = 0; j < 8; j++) t[j] = term[min(k + j, 1023)];
@@ -2377,7 +2413,7 @@ void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, 
                      double *rvel, long ray0)
 {
     size_t lds = (size_t)((sp.turb ? 3 * 1024 : 1024) + sp.n_vel * (sp.turb ? 2 : 1)) * sizeof(double) + (size_t)sp.n_vel * 16
-               + (size_t)sp.n_sub * 80;          // terms, accumulators, BinRec per bin, SpecSub per sub-beam
+               + (size_t)sp.n_sub * 80 + 129 * sizeof(float);      // terms, accumulators, BinRec per bin, SpecSub per sub-beam, suffix maxima
     hipLaunchKernelGGL(k_spectrum, dim3((unsigned)((long)n_rays * sp.n_gates)), dim3(64), lds, s, ct, sp, nu, vals, plane,
                        elev, mask, wsub, phi_sc, varray, raw, d_axis, spectrum, rvel, ray0);
 }
