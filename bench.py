@@ -41,8 +41,7 @@ N_D = 1024
 FLOP_PER_UNIT = 27 * N_D          # 12 components x (mul + add) + 3 for N(D), per diameter bin
 FLOP_PER_UNIT_DOP2 = 6 * N_D      # Doppler scheme 2: two more columns (N rcs, N v rcs), mul + add + weight each
 
-# The reference's five option files as workloads (sizes as the survey of the reference restates them); C4 is the
-# headline.  kind: scan type; rays: (n_sweeps, rays per sweep).
+# The reference's five option files (option_files/*.yml) as workloads; C4 is the headline.  kind: scan type; rays: (n_sweeps, rays per sweep).
 WORKLOADS = {
     'C1': dict(name='test_strat PPI', kind='ppi', mp=1, gh=1, dop=1, freq=5.6, rng=50000, res=75, bw=1.45,
                elevations=[1.0], az_step=1.45, coords=[46.04079, 8.83321, 2050]),
