@@ -729,6 +729,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         SpecParams sp;
         memset(&sp, 0, sizeof(sp));
         sp.n_gates = G; sp.n_sub = B; sp.n_vel = ctx->n_vel; sp.zfac = op.zfac;
+        sp.chain_cut = ctx->certified_cutoff ? 1 : 0;
         if (ctx->turb) {
             bool have_edr = false;
             for (int i = 0; i < ctx->nv; i++) have_edr = have_edr || ctx->var_ids[i] == CPOL_V_EDR;

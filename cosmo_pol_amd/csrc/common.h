@@ -219,6 +219,7 @@ struct SpecParams {
     double inv_alpha[3], inv_beta[3];   // get_D_from_V: (1/alpha * v)^(1/beta)
     float  mu[3], nu[3];
     double geo_step[3];            // diameter step when nu = 1 on an equally spaced axis, else 0
+    int    chain_cut;              // end a bin's float accumulation where the remaining terms cannot change the sum
     // turbulence broadening (off when turb == 0)
     int    turb;
     double sigma_r, sigma_theta;   // radial resolution [m], 3 dB beamwidth [rad]

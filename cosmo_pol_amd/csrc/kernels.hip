@@ -2245,7 +2245,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
                                     int ib = (int)((Db[jc] - sp.d_min[jc]) / sp.step[jc]);
                                     br.ia[jc] = (short)min(max(ia, 0), 1024);
                                     br.ib[jc] = (short)min(max(ib, 0), 1024);
-                                    has_long[jc] = has_long[jc] || br.ib[jc] - br.ia[jc] >= SPEC_LONG_BIN;
+                                    has_long[jc] = has_long[jc] || (sp.chain_cut && br.ib[jc] - br.ia[jc] >= SPEC_LONG_BIN);
                                 }
                             }
                         }

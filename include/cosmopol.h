@@ -133,7 +133,10 @@ int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *do
  * share of the sum that any lambda can leave beyond that point, and takes the smallest E for which this share is
  * below 2^-28 (a sixteenth of float32's resolution) everywhere; tables that admit no such E keep the exact-zero
  * rule.  certified = 0 switches to the exact-zero rule for every class.  cpol_get_term_cutoff returns E per class
- * (150 = exact zeros only, 0 = no table uploaded).  No counterpart in the reference. */
+ * (150 = exact zeros only, 0 = no table uploaded).  The same switch governs a shortcut of the Doppler spectrum
+ * (doppler_c.c:24-26, a float accumulator per velocity bin): with certified != 0 the accumulation of a long bin
+ * ends where every term still to come is below 2^-27 of the float sum, which none of them can change - the
+ * spectrum is bit for bit the one of certified = 0.  No counterpart in the reference. */
 int cpol_set_term_cutoff(cpol_ctx *ctx, int certified);
 int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES]);
 

@@ -324,6 +324,34 @@ def test_doppler_spectrum_vs_oracle(n_gates, n_sub):
     check_rvel(rvel, want_v.values['RVEL'], rv_atol)
 
 
+def test_spectrum_chain_cut_is_exact():
+    """doppler_c.c:24-26 adds a bin's terms to a float accumulator one after the other.  Where a bin holds 256
+    diameters or more (low elevations: the whole size range falls into one or two velocity bins) the kernel ends
+    the accumulation once every term still to come is below 2^-27 of the sum.  Such terms cannot change a float
+    sum, so the spectra with and without the shortcut are the same bits."""
+    conf = O.make_config(microphysics={'scheme': 1}, doppler={'scheme': 3},
+                         radar={'frequency': 5.6, 'radial_resolution': 250., 'PRI': 1000, 'FFT_length': 128})
+    eng = make_engine(conf)
+    for elevation, seed in ((0.7, 5), (2.0, 6), (12.0, 7)):
+        beams = syn.synthetic_beams(48, 9, 1, seed=seed, res=250., elevation=elevation, nan_tail=3, below_head=1)
+        rng = np.random.default_rng(seed)
+        for b in beams:                     # contents over six decades: short and long tails of N(D)
+            for k, v in b['values'].items():
+                if k.startswith('Q') and k.endswith('_v'):
+                    v *= (10. ** rng.uniform(-5, 1, v.shape)).astype(np.float32)
+        arrays = beams_to_arrays(beams)
+        eng.ctx.set_term_cutoff(True)
+        _, _, rvel1 = eng.ctx.observables_from_beams(*arrays)
+        spec1 = np.array(eng.ctx.last_spectrum)
+        eng.ctx.set_term_cutoff(False)
+        _, _, rvel0 = eng.ctx.observables_from_beams(*arrays)
+        spec0 = np.array(eng.ctx.last_spectrum)
+        eng.ctx.set_term_cutoff(True)
+        assert np.isfinite(spec0).any() and (spec0[np.isfinite(spec0)] > 0).any()
+        np.testing.assert_array_equal(spec1.view(np.int64), spec0.view(np.int64))
+        np.testing.assert_array_equal(np.asarray(rvel1).view(np.int64), np.asarray(rvel0).view(np.int64))
+
+
 def _beams_with_edr(n_gates, n_sub, seed):
     beams = syn.synthetic_beams(n_gates, n_sub, 1, seed=seed, res=250., elevation=12.0, nan_tail=4, below_head=2)
     rng = np.random.default_rng(seed)
