@@ -1848,7 +1848,12 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
 }
 
 // Stage 1, one thread per (ray, gate): sub-beam and class sums, observables without the range scans.
-__global__ __launch_bounds__(256, 6)
+// Launch shape by measurement (whole volume | an eighth of it, ms): 256 threads x 6 wavefronts per SIMD 1.18 | 0.236,
+// 64 x 6 1.12 | 0.230, 64 x 8 1.20 | 0.207, 64 x 7 1.10 | 0.195: small workgroups drain evenly at the end of the grid, and
+// the threads wait on dependent loads, so a seventh wavefront per SIMD is worth the 72-register limit.
+#define GR_THREADS 64
+#define GR_OCC 7
+__global__ __launch_bounds__(GR_THREADS, GR_OCC)
 void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
@@ -2025,7 +2030,7 @@ void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel)
 {
     const long n = (long)n_rays * op.n_gates;
-    hipLaunchKernelGGL(k_gate_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, n_rays, nu, key, coef,
+    hipLaunchKernelGGL(k_gate_reduce, dim3((unsigned)((n + GR_THREADS - 1) / GR_THREADS)), dim3(GR_THREADS), 0, s, op, n_rays, nu, key, coef,
                        psd_out, mask, weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
     hipLaunchKernelGGL(k_ray_scan, dim3(n_rays), dim3(64), 0, s, op, obs, obs_plane, ray0, rvel_out, spectrum,
                        n_vel);
