@@ -294,6 +294,7 @@ def main(argv=None):
     ap.add_argument('--gh', type=int, default=None, help='Gauss-Hermite nodes per direction: 3 = the 9 sub-beams of the headline '
                     'workload, 9 = the 81 sub-beams of the literal CH_PPI_lema.yml (secondary run)')
     ap.add_argument('--turbulence', type=int, choices=[0, 1], default=0, help='C5: turbulence broadening of the spectrum')
+    ap.add_argument('--host-batches', type=str, default=None, help='N,F: batch schedule of the host-delivery measurement (cpol_set_host_batching)')
     ap.add_argument('--batch-units', type=int, default=0, help='positions per internal batch (0 = library default)')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
     ap.add_argument('--stub-engine', action='store_true',
@@ -445,26 +446,50 @@ def main(argv=None):
                                        last['rvel'].nan_to_num())) and tuple(volume['obs'].shape) == (len(azs), 9, G)
 
     # second measurement at N = 1: the same steps with the outputs delivered to (pinned) host memory, the copy of
-    # one batch of rays running beside the kernels of the next
+    # one batch of rays running beside the kernels of the next (batches shrinking geometrically, so that the last
+    # batch's copy, the only one nothing hides, is short)
     host = None
     if timed and world == 1 and not args.no_host_copy:
         hb = runner.outputs(R, pinned_host=True)
         hs = runner.struct(hb)
         az_np, el_np = np.ascontiguousarray(azs[mine]), np.ascontiguousarray(elv[mine])
-        if not args.batch_units:
-            runner.ctx.set_batch_units(max(1 << 20, (R * runner.n_sub * G + 3) // 4))      # four batches per volume
+        if args.host_batches:
+            nb_, lf_ = args.host_batches.split(',')
+            runner.ctx.set_host_batching(int(nb_), float(lf_))
+        # (a) one blocking call per volume (cpol_run_rays): returns when the volume is in host memory
         runner.run_host(az_np, el_np, hs)
         runner.sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             runner.run_host(az_np, el_np, hs)
+        dtb = time.perf_counter() - t0
+        names = ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height')
+        same = all(torch.equal(hb[k].nan_to_num(), last[k].cpu().nan_to_num()) for k in names)
+        # (b) the same K volumes queued one after the other (cpol_run_rays_async, two host buffer sets): volume k - 1
+        # is awaited, and could be consumed, while volume k runs; the K-th delivery ends inside the timed region
+        hb2 = runner.outputs(R, pinned_host=True)
+        hsets, hstructs = [hb, hb2], [hs, runner.struct(hb2)]
+        runner.ctx.set_host_batching(1, 0.)
+        for k in range(2):
+            runner.ctx.run_rays_async(az_t.data_ptr(), el_t.data_ptr(), R, hstructs[k])
+        runner.sync()
+        for b in hsets:
+            b['obs'].fill_(-1.)
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            runner.ctx.run_rays_async(az_t.data_ptr(), el_t.data_ptr(), R, hstructs[k % 2])
+            if k:
+                runner.ctx.wait_async(1)
+        runner.sync()
         dth = time.perf_counter() - t0
-        same = all(torch.equal(hb[k].nan_to_num(), last[k].cpu().nan_to_num()) for k in ('obs', 'rvel', 'mask', 'lat', 'height'))
+        same = same and all(torch.equal(b[k].nan_to_num(), last[k].cpu().nan_to_num()) for k in names for b in hsets[:min(2, args.steps)])
+        runner.ctx.set_host_batching(4, 0.25)
         host = {'ms_per_step_host': dth / args.steps * 1e3, 'value_host': len(azs) * G * args.steps / dth,
+                'host_delivery': 'K volumes queued back to back (cpol_run_rays_async), the outputs of one travelling to '
+                                 'page-locked host memory beside the kernels of the next; all K deliveries inside the timed region',
+                'ms_per_call_host_blocking': dtb / args.steps * 1e3,
                 'host_outputs_equal_device_outputs': bool(same),
                 'host_bytes_per_step': int(sum(v.numel() * v.element_size() for v in hb.values()))}
-        if not args.batch_units:
-            runner.ctx.set_batch_units(32 << 20)
 
     if rank == 0:
         gates_per_step = len(azs) * G * (1 if strong else world)

@@ -56,8 +56,8 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_model_range_certified', 'cpol_set_batch_units', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
-           'cpol_run_rays', 'cpol_run_rays_dev', 'cpol_run_rays_static', 'cpol_geolocate', 'cpol_interp_points',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_model_range_certified', 'cpol_set_batch_units', 'cpol_set_host_batching', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_run_rays', 'cpol_run_rays_async', 'cpol_wait_async', 'cpol_run_rays_dev', 'cpol_run_rays_static', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
 _lib = None
@@ -84,6 +84,7 @@ def load():
     lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
     lib.cpol_timing_work.argtypes = [vp, c_double_p, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
+    lib.cpol_set_host_batching.argtypes = [vp, C.c_int, C.c_double]
     lib.cpol_set_term_cutoff.argtypes = [vp, C.c_int]
     lib.cpol_get_term_cutoff.argtypes = [vp, c_float_p]
     lib.cpol_model_range_certified.argtypes = [vp]
@@ -97,6 +98,8 @@ def load():
     lib.cpol_set_refraction_table.argtypes = [vp, C.c_int, c_double_p, c_float_p, c_float_p, c_float_p]
     lib.cpol_run_rays.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_run_rays_dev.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
+    lib.cpol_run_rays_async.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
+    lib.cpol_wait_async.argtypes = [vp, C.c_int]
     lib.cpol_run_rays_static.argtypes = [vp, C.c_int, vp, vp, C.POINTER(CpolOutputs)]
     lib.cpol_geolocate.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_float_p, c_float_p, c_float_p,
                                    c_double_p, c_double_p, c_float_p, c_int_p]
@@ -206,6 +209,10 @@ class Context(object):
 
     def set_batch_units(self, n):
         self._check(self.lib.cpol_set_batch_units(self.h, int(n)), 'cpol_set_batch_units')
+
+    def set_host_batching(self, n_batches, last_fraction):
+        """Batches per run_rays call and the share of the rays that the last, small one takes."""
+        self._check(self.lib.cpol_set_host_batching(self.h, int(n_batches), float(last_fraction)), 'cpol_set_host_batching')
 
     # -- state ---------------------------------------------------------------------
     def set_config(self, **kw):
@@ -323,6 +330,16 @@ class Context(object):
         rc = self.lib.cpol_run_rays_dev(self.h, int(n_rays), int(az_ptr), int(el_ptr), C.byref(o))
         self._check(rc, 'cpol_run_rays_dev')
         return o
+
+    def run_rays_async(self, az_ptr, el_ptr, n_rays, host_outputs):
+        """cpol_run_rays_async: queue one scan with its outputs delivered to the (page-locked) host buffers of
+        host_outputs; synchronize() waits for the kernels and deliveries of every call so far."""
+        rc = self.lib.cpol_run_rays_async(self.h, int(n_rays), int(az_ptr), int(el_ptr), C.byref(host_outputs))
+        self._check(rc, 'cpol_run_rays_async')
+
+    def wait_async(self, calls_back=0):
+        """Wait for the delivery of the most recent run_rays_async call (0) or of the one before it (1)."""
+        self._check(self.lib.cpol_wait_async(self.h, int(calls_back)), 'cpol_wait_async')
 
     def run_rays_static(self, az_dev_ptr, el_dev_ptr, n_rays, outputs=None):
         """cpol_run_rays_static: the allocation-free variant of run_rays_dev (device arrays in, every workspace from

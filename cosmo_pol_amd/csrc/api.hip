@@ -4,6 +4,7 @@
 #include <math.h>
 #include <string.h>
 #include <mutex>
+#include <algorithm>
 
 static int fail(cpol_ctx *ctx, int code, const char *msg);
 
@@ -177,6 +178,14 @@ extern "C" int cpol_set_batch_units(cpol_ctx *ctx, long max_units)
     return CPOL_OK;
 }
 
+extern "C" int cpol_set_host_batching(cpol_ctx *ctx, int n_batches, double last_fraction)
+{
+    if (!ctx || n_batches < 1 || n_batches > 64 || !(last_fraction >= 0.) || last_fraction > 1.) return CPOL_ERR_ARG;
+    ctx->host_batches = n_batches;
+    ctx->host_last_fraction = last_fraction;
+    return CPOL_OK;
+}
+
 static int fail(cpol_ctx *ctx, int code, const char *msg)
 {
     if (ctx) ctx->err = msg;
@@ -223,6 +232,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     // teardown: nothing useful can be done about a failing free, so the statuses are dropped on purpose
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (auto *b : ctx->bufs) if (b->p) (void)hipFree(b->p);
     if (ctx->zcol) (void)hipFree(ctx->zcol);
     if (ctx->zc8) (void)hipFree(ctx->zc8);
@@ -240,6 +250,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_events) (void)hipEventDestroy(e);
+    for (auto e : ctx->async_done) if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->valid_host) (void)hipHostFree(ctx->valid_host);
     (void)hipStreamDestroy(ctx->stream);
@@ -254,6 +265,7 @@ extern "C" int cpol_synchronize(cpol_ctx *ctx)
 {
     if (!ctx) return CPOL_ERR_ARG;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));      // deliveries of cpol_run_rays_async
     timing_collect(ctx);
     return CPOL_OK;
 }
@@ -801,14 +813,24 @@ static int ensure_geom(cpol_ctx *ctx, long nrb, long nu, bool points_too = true)
 // The hot path for n_rays rays.  no_alloc = false: the workspaces are the ctx's grow-only heap buffers and the
 // rays go through in batches.  no_alloc = true (cpol_run_rays_static): ctx->arena is set, every workspace is a
 // piece of the static scratch, azimuth / elevation are device arrays used in place, and nothing is allocated.
-// Queue the device-to-host copies of rays [r0, r0 + nr) of every requested output on the copy stream, behind
-// the event that marks the end of their batch on the compute stream.
+// Queue device-to-host copies of rays [r0, r0 + nr) on the copy stream, behind the event that marks the point of
+// the compute stream at which they are final.  part 0: the central sub-beam's geometry (lat, lon, dist, height),
+// which the front kernel of a batch writes; part 1: everything the last kernels of the batch write.
 static int copy_batch_to_host(cpol_ctx *ctx, const cpol_outputs &d, const cpol_outputs &h, int n_rays, int r0, int nr,
-                              hipEvent_t done)
+                              hipEvent_t done, int part)
 {
     const size_t G = ctx->cfg.n_gates, RG = (size_t)n_rays * G, o = (size_t)r0 * G, n = (size_t)nr * G;
     hipStream_t s = ctx->copy_stream;
     HIPCHK(ctx, hipStreamWaitEvent(s, done, 0));
+    if (part == 0) {
+        if (h.lat) HIPCHK(ctx, hipMemcpyAsync(h.lat + o, d.lat + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (h.lon) HIPCHK(ctx, hipMemcpyAsync(h.lon + o, d.lon + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (h.dist) HIPCHK(ctx, hipMemcpyAsync(h.dist + o, d.dist + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (h.height) HIPCHK(ctx, hipMemcpyAsync(h.height + o, d.height + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        return CPOL_OK;
+    }
+    // (one copy per field: a single hipMemcpy2DAsync of the nine rows measured 18 GB/s on rows of 7 MB where these
+    // copies move 53 GB/s)
     if (h.obs)
         for (int f = 0; f < CPOL_N_OBS; f++)
             HIPCHK(ctx, hipMemcpyAsync(h.obs + f * RG + o, d.obs + f * RG + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -817,18 +839,23 @@ static int copy_batch_to_host(cpol_ctx *ctx, const cpol_outputs &d, const cpol_o
         HIPCHK(ctx, hipMemcpyAsync(h.dspectrum + o * ctx->n_vel, d.dspectrum + o * ctx->n_vel, n * ctx->n_vel * sizeof(double),
                                    hipMemcpyDeviceToHost, s));
     if (h.mask) HIPCHK(ctx, hipMemcpyAsync(h.mask + o, d.mask + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (h.lat) HIPCHK(ctx, hipMemcpyAsync(h.lat + o, d.lat + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (h.lon) HIPCHK(ctx, hipMemcpyAsync(h.lon + o, d.lon + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (h.dist) HIPCHK(ctx, hipMemcpyAsync(h.dist + o, d.dist + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (h.height) HIPCHK(ctx, hipMemcpyAsync(h.height + o, d.height + o, n * sizeof(float), hipMemcpyDeviceToHost, s));
     if (h.ray_status) HIPCHK(ctx, hipMemcpyAsync(h.ray_status + r0, d.ray_status + r0, nr * sizeof(int), hipMemcpyDeviceToHost, s));
     return CPOL_OK;
+}
+
+// True when p lies in page-locked host memory (hipHostMalloc / hipHostRegister): copies into it are asynchronous.
+static bool is_pinned_host(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }
 
 // host (may be NULL): host buffers that receive the outputs batch by batch, the copy of one batch on a second
 // stream beside the kernels of the next.
 static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
-                         cpol_outputs *out, bool no_alloc, const cpol_outputs *host = nullptr)
+                         cpol_outputs *out, bool no_alloc, const cpol_outputs *host = nullptr, bool async_delivery = false)
 {
     ClassTable ct;
     TRY(build_class_table(ctx, ct, !no_alloc));
@@ -875,8 +902,29 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
     int rays_per_batch = (int)(ctx->max_batch_units / per_ray);
     if (rays_per_batch < 1) rays_per_batch = 1;
     if (rays_per_batch > n_rays || no_alloc) rays_per_batch = n_rays;
-    long nu_max = (long)rays_per_batch * per_ray;
-    TRY(ensure_geom(ctx, (long)rays_per_batch * B, nu_max, false));
+    // Batch schedule.  Device outputs: as few batches as the workspace limit allows.  Host delivery: the outputs
+    // of a batch leave on the copy stream beside the kernels of the next, so only the last batch's copy is not
+    // hidden: host_batches batches, the last one a small one (host_last_fraction of the rays, but about 1 Mi
+    // positions at least: a batch has fixed costs), the others equal.
+    std::vector<int> sched;
+    {
+        int nb_host = 1, last = 0;
+        if (host && ctx->host_batches > 1) {
+            const int min_rays = (int)std::max<long>(1, ((1L << 20) + per_ray - 1) / per_ray);
+            last = std::max(min_rays, (int)(n_rays * ctx->host_last_fraction));
+            nb_host = ctx->host_batches;
+            if (last * nb_host > n_rays) { nb_host = 1; last = 0; }      // too small a call to split
+        }
+        const int body = n_rays - last;
+        int per = nb_host > 1 ? (body + nb_host - 2) / (nb_host - 1) : body;
+        if (per > rays_per_batch) per = rays_per_batch;
+        for (int left = body; left > 0; left -= per) sched.push_back(left < per ? left : per);
+        if (last) sched.push_back(last);
+    }
+    long nu_max = 0;
+    for (int nr : sched) nu_max = std::max(nu_max, (long)nr * per_ray);
+    const int nr_max = (int)(nu_max / per_ray);
+    TRY(ensure_geom(ctx, (long)nr_max * B, nu_max, false));
     TRY(ensure(ctx, w.b_vals, (size_t)CPOL_V_COUNT * nu_max * sizeof(float)));
     TRY(ensure(ctx, w.b_mask, nu_max));
     GeomParams gp;
@@ -890,57 +938,90 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
         vr1_mask |= 1u << ct.dop[h].q_var | 1u << ct.dop[h].t_var;
         if (ct.dop[h].qn_var >= 0) vr1_mask |= 1u << ct.dop[h].qn_var;
     }
-    if (host && !ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // What reaches the host: rvel only with a Doppler scheme (without one the device buffer is never written).
+    cpol_outputs hd;
+    memset(&hd, 0, sizeof(hd));
+    bool early_geometry = false;
+    if (host) {
+        hd = *host;
+        if (!ctx->cfg.doppler_scheme) hd.rvel = nullptr;
+        if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        // a copy into pageable memory blocks the host until it is done: such copies are queued only once the GPU
+        // has its next batch; page-locked buffers take the geometry as soon as the front kernel has written it
+        early_geometry = is_pinned_host(hd.lat) && is_pinned_host(hd.lon) && is_pinned_host(hd.dist) && is_pinned_host(hd.height)
+                         && is_pinned_host(hd.obs);
+        while (ctx->copy_events.size() < 2 * sched.size()) {
+            hipEvent_t e;
+            HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->copy_events.push_back(e);
+        }
+    }
     int prev_r0 = -1, prev_nr = 0, n_batch = 0;
     hipEvent_t prev_done = nullptr;
-    for (int r0 = 0; r0 < n_rays; r0 += rays_per_batch) {
-        int nr = n_rays - r0 < rays_per_batch ? n_rays - r0 : rays_per_batch;
-        long nu = (long)nr * per_ray;
-        {
-            // geometry of the points, interpolation and PSD set-up in one kernel; the variables that a later
-            // kernel reads are the only ones that reach memory
-            StageTimer t_(ctx, CPOL_ST_INTERP);
-            TRY(ensure_physics(ctx, ct, nu));
-            TRY(clear_hist(ctx, ct));
-            FrontOut fo;
-            memset(&fo, 0, sizeof(fo));
-            fo.E = (float *)w.b_E.p; fo.mask = (signed char *)w.b_mask.p;
-            fo.vals = (float *)w.b_vals.p; fo.plane = nu_max;
-            const int ds = ctx->cfg.doppler_scheme;
-            fo.write_mask = ds == 3 ? ~0u
-                          : ds == 2 ? (1u << CPOL_V_RHO | 1u << CPOL_V_U | 1u << CPOL_V_V | 1u << CPOL_V_W)
-                          : ds == 1 ? vr1_mask : 0u;
-            fo.dist = out->dist; fo.height = out->height; fo.lat = out->lat; fo.lon = out->lon;
-            fo.ray0 = r0; fo.status = status + r0;
-            fo.key = (cpol_key_t *)w.b_key.p; fo.rank = (int *)w.b_rank.p; fo.lam = (float2 *)w.b_lam.p;
-            fo.coef = (double *)w.b_coef.p; fo.n0d = (double *)w.b_n0d.p; fo.hist = (int *)w.b_hist.p;
-            launch_front(ctx->stream, gp, mv, ct, nr, az_dev + r0, el_dev + r0, ctx->quad_dev, (double *)w.b_line.p,
-                         (double *)w.b_phi.p, wsub, ds == 3 ? 0 : ds, fo);
-        }
-        TRY(run_physics(ctx, ct, nr, B, G, (const float *)w.b_vals.p, nu_max, (const float *)w.b_E.p,
-                        (const signed char *)w.b_mask.p, wsub, (const double *)w.b_phi.p,
-                        out->obs, RG, r0, out->mask, out->rvel, out->dspectrum, true));
-        if (host) {
-            // this batch's kernels are queued: now hand the previous batch to the copy stream (a copy into
-            // pageable memory blocks the host, which by then has given the GPU its next batch)
-            if ((size_t)n_batch == ctx->copy_events.size()) {
-                hipEvent_t e;
-                HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                ctx->copy_events.push_back(e);
+    int rc = CPOL_OK;
+    auto batches = [&]() -> int {
+        int r0 = 0;
+        for (int nr : sched) {
+            long nu = (long)nr * per_ray;
+            {
+                // geometry of the points, interpolation and PSD set-up in one kernel; the variables that a later
+                // kernel reads are the only ones that reach memory
+                StageTimer t_(ctx, CPOL_ST_INTERP);
+                TRY(ensure_physics(ctx, ct, nu));
+                TRY(clear_hist(ctx, ct));
+                FrontOut fo;
+                memset(&fo, 0, sizeof(fo));
+                fo.E = (float *)w.b_E.p; fo.mask = (signed char *)w.b_mask.p;
+                fo.vals = (float *)w.b_vals.p; fo.plane = nu_max;
+                const int ds = ctx->cfg.doppler_scheme;
+                fo.write_mask = ds == 3 ? ~0u
+                              : ds == 2 ? (1u << CPOL_V_RHO | 1u << CPOL_V_U | 1u << CPOL_V_V | 1u << CPOL_V_W)
+                              : ds == 1 ? vr1_mask : 0u;
+                fo.dist = out->dist; fo.height = out->height; fo.lat = out->lat; fo.lon = out->lon;
+                fo.ray0 = r0; fo.status = status + r0;
+                fo.key = (cpol_key_t *)w.b_key.p; fo.rank = (int *)w.b_rank.p; fo.lam = (float2 *)w.b_lam.p;
+                fo.coef = (double *)w.b_coef.p; fo.n0d = (double *)w.b_n0d.p; fo.hist = (int *)w.b_hist.p;
+                launch_front(ctx->stream, gp, mv, ct, nr, az_dev + r0, el_dev + r0, ctx->quad_dev, (double *)w.b_line.p,
+                             (double *)w.b_phi.p, wsub, ds == 3 ? 0 : ds, fo);
             }
-            hipEvent_t done = ctx->copy_events[n_batch++];
-            HIPCHK(ctx, hipEventRecord(done, ctx->stream));
-            if (prev_done) TRY(copy_batch_to_host(ctx, *out, *host, n_rays, prev_r0, prev_nr, prev_done));
-            prev_done = done; prev_r0 = r0; prev_nr = nr;
+            if (host && early_geometry) {
+                // the previous batch's results first (their event comes first on the compute stream), then this
+                // batch's geometry
+                if (prev_done) { TRY(copy_batch_to_host(ctx, *out, hd, n_rays, prev_r0, prev_nr, prev_done, 1)); prev_done = nullptr; }
+                hipEvent_t fr = ctx->copy_events[2 * n_batch];
+                HIPCHK(ctx, hipEventRecord(fr, ctx->stream));
+                TRY(copy_batch_to_host(ctx, *out, hd, n_rays, r0, nr, fr, 0));
+            }
+            TRY(run_physics(ctx, ct, nr, B, G, (const float *)w.b_vals.p, nu_max, (const float *)w.b_E.p,
+                            (const signed char *)w.b_mask.p, wsub, (const double *)w.b_phi.p,
+                            out->obs, RG, r0, out->mask, out->rvel, out->dspectrum, true));
+            if (host) {
+                hipEvent_t done = ctx->copy_events[2 * n_batch + 1];
+                HIPCHK(ctx, hipEventRecord(done, ctx->stream));
+                if (prev_done) {       // pageable host buffers: this batch's kernels are queued, now the previous batch may block the host
+                    TRY(copy_batch_to_host(ctx, *out, hd, n_rays, prev_r0, prev_nr, prev_done, 0));
+                    TRY(copy_batch_to_host(ctx, *out, hd, n_rays, prev_r0, prev_nr, prev_done, 1));
+                }
+                prev_done = done; prev_r0 = r0; prev_nr = nr;
+            }
+            n_batch++;
+            r0 += nr;
         }
-    }
-    HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipGetLastError());
+        if (host && prev_done) {
+            if (!early_geometry) TRY(copy_batch_to_host(ctx, *out, hd, n_rays, prev_r0, prev_nr, prev_done, 0));
+            TRY(copy_batch_to_host(ctx, *out, hd, n_rays, prev_r0, prev_nr, prev_done, 1));
+        }
+        return CPOL_OK;
+    };
+    rc = batches();
     if (!ctx->cfg.doppler_scheme) out->rvel = nullptr;
-    if (host && prev_done) {
-        TRY(copy_batch_to_host(ctx, *out, *host, n_rays, prev_r0, prev_nr, prev_done));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (host && ctx->copy_stream && !(async_delivery && rc == CPOL_OK)) {
+        // also on failure: copies already queued write into the caller's buffers, which must not outlive this call
+        const hipError_t e = hipStreamSynchronize(ctx->copy_stream);
+        if (rc == CPOL_OK) HIPCHK(ctx, e);
     }
-    return CPOL_OK;
+    return rc;
 }
 
 extern "C" int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
@@ -991,6 +1072,50 @@ extern "C" int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, c
     TRY(run_rays_impl(ctx, n_rays, azimuth, elevation, &d, false, host));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     timing_collect(ctx);
+    return CPOL_OK;
+}
+
+extern "C" int cpol_run_rays_async(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                                   cpol_outputs *host)
+{
+    if (!host) return CPOL_ERR_ARG;
+    TRY(check_ready(ctx, true, true));
+    if (n_rays == 0) return CPOL_OK;
+    if (n_rays < 0 || !azimuth || !elevation) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the device outputs of this call: the set that the call before the last one used
+    const int slot = ctx->async_slot;
+    ctx->async_slot ^= 1;
+    cpol_ctx::Buf *b = ctx->async_out[slot];
+    const size_t RG = (size_t)n_rays * ctx->cfg.n_gates;
+    cpol_outputs d;
+    memset(&d, 0, sizeof(d));
+    TRY(ensure(ctx, b[0], CPOL_N_OBS * RG * sizeof(float)));  d.obs = (float *)b[0].p;
+    TRY(ensure(ctx, b[1], RG * sizeof(double)));              d.rvel = (double *)b[1].p;
+    TRY(ensure(ctx, b[2], RG * sizeof(double)));              d.mask = (double *)b[2].p;
+    TRY(ensure(ctx, b[3], RG * sizeof(double)));              d.lat = (double *)b[3].p;
+    TRY(ensure(ctx, b[4], RG * sizeof(double)));              d.lon = (double *)b[4].p;
+    TRY(ensure(ctx, b[5], RG * sizeof(float)));               d.dist = (float *)b[5].p;
+    TRY(ensure(ctx, b[6], RG * sizeof(float)));               d.height = (float *)b[6].p;
+    TRY(ensure(ctx, b[7], (size_t)n_rays * sizeof(int)));     d.ray_status = (int *)b[7].p;
+    if (ctx->cfg.doppler_scheme == 3 && ctx->n_vel >= 2) {
+        TRY(ensure(ctx, b[8], RG * ctx->n_vel * sizeof(double)));
+        d.dspectrum = (double *)b[8].p;
+    }
+    // what the set held before must have left for the host before this call's kernels write into it
+    if (ctx->async_done[slot]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->async_done[slot], 0));
+    TRY(run_rays_impl(ctx, n_rays, azimuth, elevation, &d, false, host, true));
+    if (!ctx->async_done[slot]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->async_done[slot], hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->async_done[slot], ctx->copy_stream));
+    return CPOL_OK;
+}
+
+extern "C" int cpol_wait_async(cpol_ctx *ctx, int calls_back)
+{
+    if (!ctx || calls_back < 0 || calls_back > 1) return CPOL_ERR_ARG;
+    // the most recent call used the set that is not next in turn
+    hipEvent_t e = ctx->async_done[(ctx->async_slot ^ 1) ^ calls_back];
+    if (e) HIPCHK(ctx, hipEventSynchronize(e));
     return CPOL_OK;
 }
 

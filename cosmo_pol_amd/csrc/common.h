@@ -116,7 +116,7 @@ struct cpol_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;         // device-to-host copies of cpol_run_rays, beside the kernels of the next batch
-    std::vector<hipEvent_t> copy_events;       // one per batch: its kernels have finished
+    std::vector<hipEvent_t> copy_events;       // two per batch: its front kernel / all its kernels have finished
     std::string err;
     bool have_cfg = false, have_model = false;
     cpol_config cfg;
@@ -156,6 +156,13 @@ struct cpol_ctx {
     char  *arena = nullptr;               // non-null while a call carves its buffers from the static scratch
     size_t arena_cap = 0, arena_off = 0;
     size_t max_batch_units = (size_t)32 << 20;     // (ray x sub-beam x gate) positions per batch
+    int    host_batches = 4;                       // cpol_run_rays: batches per call
+    double host_last_fraction = 0.25;              // share of the rays that the last batch takes
+    // cpol_run_rays_async: two sets of device output buffers used in turn, and per set the event on the copy stream
+    // after which its previous contents have left for the host
+    Buf async_out[2][10];
+    hipEvent_t async_done[2] = {nullptr, nullptr};
+    int async_slot = 0;
     // optional stage timing (hipEvents on ctx->stream) and work counters
     bool   certified_cutoff = true;               // term cutoffs below the exact-zero one where the tables carry a certificate
     float *cert_dev = nullptr;                    // result word of k_cut_certificate

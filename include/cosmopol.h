@@ -99,6 +99,7 @@ int  cpol_destroy(cpol_ctx *ctx);
 const char *cpol_last_error(cpol_ctx *ctx);
 /* HIP stream all kernels of this ctx are launched on (a hipStream_t), for event timing. */
 void *cpol_stream(cpol_ctx *ctx);
+/* Waits for every kernel and every device-to-host delivery queued by this ctx. */
 int  cpol_synchronize(cpol_ctx *ctx);
 
 /* ---- measurement -------------------------------------------------------------------- */
@@ -150,6 +151,13 @@ int cpol_model_range_certified(cpol_ctx *ctx);
  * workspace the library allocates (default 32 Mi positions, about 26 GB with 2-moment input and Doppler scheme 2,
  * allocated only as far as a call needs it; at most 128 Mi). */
 int cpol_set_batch_units(cpol_ctx *ctx, long max_units);
+/* Batch schedule of cpol_run_rays, which delivers the outputs to host memory the way the reference's pool hands the
+ * beams back to the parent (radar_operator.py:255-256): the outputs of one batch of rays travel to the host beside the
+ * kernels of the next, so only the last batch's copy is not hidden.  A call is split into n_batches batches, the last
+ * one taking last_fraction of the rays (about 1 Mi positions at least), the others equal shares of the rest and never
+ * more than cpol_set_batch_units allows; n_batches = 1: no split.  The results do not depend on it.  No counterpart in
+ * the reference. */
+int cpol_set_host_batching(cpol_ctx *ctx, int n_batches, double last_fraction);
 
 /* ---- state -------------------------------------------------------------------------- */
 /* utilities/cfg.py CONFIG + constants.update() (radar_operator.py:39-40). */
@@ -228,6 +236,21 @@ int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double
                   cpol_outputs *host_out);
 int cpol_run_rays_dev(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
                       cpol_outputs *dev_out);
+
+/* cpol_run_rays for a caller that simulates one scan after the other (a sequence of model states, the radars of a
+ * network): the call returns as soon as its kernels and its device-to-host copies are queued, so the outputs of one
+ * scan travel to the host beside the kernels of the next - the pool of radar_operator.py:253-256 kept busy across
+ * scans.  host_out must stay valid, and should be page-locked (a copy into pageable memory makes the call wait for
+ * it), until cpol_synchronize() has returned, which waits for the kernels and the deliveries of every call so far;
+ * ray_status is to be read after that.  azimuth / elevation may be host or device arrays and are read before the
+ * call returns.  Two sets of device output buffers are used in turn, so any number of calls may be queued: the
+ * third waits on the device for the first one's delivery. */
+int cpol_run_rays_async(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
+                        cpol_outputs *host_out);
+/* Waits until the outputs of the most recent cpol_run_rays_async call (calls_back = 0) or of the one before it
+ * (calls_back = 1) are in host memory: with two host buffer sets a consumer queues scan k, waits for scan k - 1 and
+ * reads it while scan k runs. */
+int cpol_wait_async(cpol_ctx *ctx, int calls_back);
 
 /* The same hot path for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same computation and same outputs as

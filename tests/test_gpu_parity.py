@@ -723,6 +723,71 @@ def test_run_rays_vs_oracle(scheme, nh, nv):
         np.testing.assert_allclose(out['lon'][r], want.lons_profile, rtol=0, atol=1e-12)
 
 
+def test_host_delivery_schedules_and_async_calls():
+    """cpol_run_rays delivers the same bits whatever its batch schedule (copies of one batch beside the kernels of the
+    next), without a Doppler scheme it leaves the caller's rvel alone in every batch, and cpol_run_rays_async - three
+    scans queued before the first wait, two sets of device buffers - delivers what the blocking call delivers."""
+    import ctypes
+    conf = pipeline_conf(2, 3, 3, dscheme=2)
+    m = pipeline_model(2)
+    eng = make_engine(conf)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    eng.set_gauss_hermite()
+    ctx = eng.ctx
+    rng = np.random.default_rng(3)
+    scans = [(rng.uniform(0, 360, n), rng.uniform(0.5, 30, n)) for n in (37, 11, 23)]
+    ctx.set_host_batching(1, 0.)
+    want = [ctx.run_rays(az, el) for az, el in scans]
+    names = ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height', 'ray_status')
+    try:
+        ctx.set_batch_units(5 * 9 * eng.n_gates)            # at most five rays per batch
+        for nb, lf in ((4, 0.25), (3, 0.05), (8, 0.5)):
+            ctx.set_host_batching(nb, lf)
+            got = ctx.run_rays(*scans[0])
+            for k in names:
+                assert got[k].tobytes() == want[0][k].tobytes(), (nb, lf, k)
+        ctx.set_batch_units(32 << 20)
+        ctx.set_host_batching(2, 0.5)
+        G = eng.n_gates
+        bufs, structs = [], []
+        for az, el in scans:
+            R = len(az)
+            b = {'obs': np.full((9, R, G), 7, np.float32), 'ray_status': np.full(R, -1, np.int32)}
+            b.update({k: np.full((R, G), 7, np.float64) for k in ('rvel', 'mask', 'lat', 'lon')})
+            b.update({k: np.full((R, G), 7, np.float32) for k in ('dist', 'height')})
+            bufs.append(b)
+            structs.append(_lib.CpolOutputs(_lib.fptr(b['obs']), _lib.dptr(b['rvel']), _lib.dptr(b['mask']), _lib.dptr(b['lat']),
+                                            _lib.dptr(b['lon']), _lib.fptr(b['dist']), _lib.fptr(b['height']),
+                                            _lib.iptr(b['ray_status']), None))
+        keep = [(np.ascontiguousarray(az), np.ascontiguousarray(el)) for az, el in scans]
+        for (az, el), st in zip(keep, structs):
+            ctx.run_rays_async(az.ctypes.data, el.ctypes.data, len(az), st)
+        ctx.synchronize()
+        for b, w in zip(bufs, want):
+            for k in names:
+                assert b[k].tobytes() == w[k].tobytes(), k
+    finally:
+        ctx.set_batch_units(32 << 20)
+        ctx.set_host_batching(4, 0.25)
+    # no Doppler scheme: rvel is not an output, whatever the number of batches
+    conf0 = pipeline_conf(2, 3, 3, dscheme=2)
+    conf0['doppler']['scheme'] = 0
+    eng.configure(conf0, doppler=0)
+    az, el = scans[0]
+    R, G = len(az), eng.n_gates
+    rv = np.full((R, G), 123.0)
+    o = {'obs': np.empty((9, R, G), np.float32), 'mask': np.empty((R, G)), 'st': np.zeros(R, np.int32)}
+    st = _lib.CpolOutputs(_lib.fptr(o['obs']), _lib.dptr(rv), _lib.dptr(o['mask']), None, None, None, None, _lib.iptr(o['st']), None)
+    ctx.set_batch_units(5 * 9 * G)
+    try:
+        rc = ctx.lib.cpol_run_rays(ctx.h, R, np.ascontiguousarray(az).ctypes.data, np.ascontiguousarray(el).ctypes.data, ctypes.byref(st))
+        assert rc == 0
+    finally:
+        ctx.set_batch_units(32 << 20)
+    assert (rv == 123.0).all()
+    assert o['obs'][0].tobytes() == want[0]['obs'][0].tobytes()
+
+
 def test_run_rays_out_of_domain():
     conf = pipeline_conf(1, 1, 1, rng=400000.)
     m = pipeline_model(1)
