@@ -71,6 +71,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # A process that also uses PyTorch-ROCm must bring torch's HIP runtime up before this library initialises the
+    # system's one (the other way round torch finds no GPU afterwards): do that for a caller who has imported torch.
+    import sys
+    torch = sys.modules.get('torch')
+    if torch is not None and hasattr(torch, 'cuda') and torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.cpol_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -370,6 +370,9 @@ static void fill_psd(PsdView &v, const cpol_psd &p)
     v.c_exp = p.psd_kind == 0 ? 1. / (4. + p.mu) : p.psd_kind == 1 ? 1. / (p.b + 1) : -p.nu / p.b;
     v.c_n = p.nu / p.ntot_factor;
     v.c_n_exp = (p.mu + 1) / p.nu;
+    v.log2_lf = log2(p.lambda_factor);
+    v.l2_const = log2(1.4426950408889634) + (p.psd_kind == 2 ? log2(v.lam_unit) : 0.);
+    v.cn_unit = v.c_n * v.n0_unit;
 }
 
 extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, const cpol_psd *psd,

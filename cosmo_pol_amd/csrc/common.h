@@ -11,7 +11,7 @@
 typedef short cpol_key_t;         // bucket (class, elevation node, temperature node) of a unit, -1 = not valid; at most 16384 buckets
 #define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
-#define CPOL_LINE_N 32            // doubles per (ray, sub-beam) record of the geodesic line constants
+#define CPOL_LINE_N 40            // doubles per (ray, sub-beam) record of the geodesic line constants
 // work counters of the two integration kernels: CPOL_WORK_SLOTS each, one per 64-byte line, so that the wavefronts
 // of a launch spread their atomics over many lines
 #define CPOL_WORK_SLOTS 1024
@@ -57,6 +57,8 @@ struct PsdView {
     // quotients of the constants above, worked out once on the host with the same float64 operations:
     double c_exp;                  // exponent of lambda: 1 / (4 + mu) | 1 / (b + 1) | -nu / b  (kind 0 | 1 | 2)
     double c_n, c_n_exp;           // kind 2: nu / ntot_factor, (mu + 1) / nu
+    // base-2 forms for psd_fast: log2(lambda_factor); log2(log2 e) plus, for kind 2, log2(lam_unit); c_n * n0_unit
+    double log2_lf, l2_const, cn_unit;
 };
 
 struct ClassTable {

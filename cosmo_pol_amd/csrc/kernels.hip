@@ -83,9 +83,9 @@ __device__ inline double ang_normalize(double x)
 
 // sin, cos, asin and atan of a small argument by their Taylor series: below SMALL_ANGLE the first term left out is
 // under 2^-55 of the result, so the value is the correctly rounded one up to the last bit, as with the
-// library routine, without its range reduction.  Every gate of a ground radar (150 km against the earth's radius)
-// takes this path; a larger argument goes to the library.
-#define SMALL_ANGLE 0.04
+// library routine, without its range reduction.  Every gate of a ground radar (ranges of a few hundred km against
+// the earth's radius) takes this path; a larger argument goes to the library.
+#define SMALL_ANGLE 0.1
 __device__ inline void sincos_small(double x, double *s, double *c)
 {
     if (fabs(x) < SMALL_ANGLE) {
@@ -95,22 +95,46 @@ __device__ inline void sincos_small(double x, double *s, double *c)
     } else sincos(x, s, c);
 }
 
-__device__ inline double asin_small(double x)
+__device__ inline double asin_series(double x)
 {
-    if (fabs(x) < SMALL_ANGLE) {
-        const double x2 = x * x;
-        return x * (1. + x2 * (1. / 6. + x2 * (3. / 40. + x2 * (15. / 336. + x2 * (105. / 3456. + x2 * (945. / 42240.))))));
-    }
-    return asin(x);
+    const double x2 = x * x;
+    return x * (1. + x2 * (1. / 6. + x2 * (3. / 40. + x2 * (15. / 336. + x2 * (105. / 3456. + x2 * (945. / 42240. +
+               x2 * (10395. / 599040. + x2 * (135135. / 9676800.))))))));
 }
 
-__device__ inline double atan_small(double x)
+__device__ inline double asin_small(double x) { return fabs(x) < SMALL_ANGLE ? asin_series(x) : asin(x); }
+
+__device__ inline double atan_series(double x)
 {
-    if (fabs(x) < SMALL_ANGLE) {
-        const double x2 = x * x;
-        return x * (1. + x2 * (-1. / 3. + x2 * (1. / 5. + x2 * (-1. / 7. + x2 * (1. / 9. + x2 * (-1. / 11. + x2 * (1. / 13.)))))));
-    }
-    return atan(x);
+    const double x2 = x * x;
+    return x * (1. + x2 * (-1. / 3. + x2 * (1. / 5. + x2 * (-1. / 7. + x2 * (1. / 9. + x2 * (-1. / 11. + x2 * (1. / 13. -
+               x2 * (1. / 15.))))))));
+}
+
+__device__ inline double atan_small(double x) { return fabs(x) < SMALL_ANGLE ? atan_series(x) : atan(x); }
+
+// 1 / d and 1 / sqrt(d) for a positive, normal, finite d: the hardware's approximation and two Newton steps, good
+// to an ulp or two of float64.  The consumers round their results to float32 or tolerate 1e-12 degrees.
+__device__ inline double rcp_fast(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+    return __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+}
+
+__device__ inline double rsqrt_fast(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
+    return y * __builtin_fma(-0.5 * d * y, y, 1.5);
+}
+
+// atan2(y, x) for the small angles of a ground radar's neighbourhood (x > 0, |y| < SMALL_ANGLE x): the series of
+// the quotient; the library routine otherwise.
+__device__ inline double atan2_small(double y, double x)
+{
+    if (x > 0. && fabs(y) < SMALL_ANGLE * x) return atan_series(y * rcp_fast(x));
+    return atan2(y, x);
 }
 
 __device__ inline void sincosd(double x, double *sx, double *cx)
@@ -245,6 +269,17 @@ __global__ void k_geom_line(GeomParams gp, int n_rays, const double *__restrict_
         L[26] = sin(ela); L[27] = cos(ela);
         const double pollat = -gp.pole_lat_s;
         L[28] = sin(pollat * DEG); L[29] = cos(pollat * DEG);
+        // reference point of the per-gate small-angle forms: the radar itself.  Longitude difference to the rotated
+        // pole (its sine and cosine), geographic latitude as the geodesic solution returns it at distance zero, and
+        // the pair (sin, f1 cos) of the reduced latitude it is the arc tangent of
+        double pollon = gp.pole_lon_s - 180.0;
+        if (pollon < -180.0) pollon += 360.0;
+        const double dl0 = (L[31] - pollon) * DEG;
+        L[32] = sin(dl0); L[33] = cos(dl0); L[37] = dl0;
+        const double sb0 = calp0 * ssig1, cb0 = hypot(salp0, calp0 * csig1);
+        L[34] = atan2d(sb0, f1 * cb0);
+        const double hn = hypot(sb0, f1 * cb0);
+        L[35] = sb0 / hn; L[36] = f1 * cb0 / hn;
     }
     if (gp.n_refr > 0) {
         // profile of this total elevation in the refraction table (exact key)
@@ -283,8 +318,8 @@ __device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, con
         const double ke = 4. / 3.;
         double keR = ke * gp.earth_radius;
         double Hd = sqrt(rr * rr + keR * keR + 2 * rr * ke * gp.earth_radius * sel) - keR + gp.alt;
-        double Sd = keR * asin_small((rr * cel) / (keR + Hd));
-        double Ed = ela + atan_small(rr * cel / (rr * sel + keR + gp.alt));
+        double Sd = keR * asin_small((rr * cel) * rcp_fast(keR + Hd));
+        double Ed = ela + atan_small(rr * cel * rcp_fast(rr * sel + keR + gp.alt));
         S = (float)Sd; H = (float)Hd;
         E = (float)Ed * (float)(180.0 / M_PI);
     }
@@ -316,27 +351,36 @@ __device__ inline void geom_point(const GeomParams &gp, const ModelView &mv, con
     double cbet2 = sqrt(salp0 * salp0 + cc2 * cc2);      // operands of order one: no scaling needed
     if (cbet2 == 0) cbet2 = csig2 = tiny;
     double somg2 = salp0 * ssig2, comg2 = csig2;
-    double omg12 = atan2(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);
+    double omg12 = atan2_small(somg2 * comg1 - comg2 * somg1, comg2 * comg1 + somg2 * somg1);
     double lam12 = omg12 + A3c * (sig12 + (sin_cos_series(ssig2, csig2, C3a, 5) - B31));
     double lon12 = lam12 * RAD2DEG;
     double lon = ang_normalize(L[31] + ang_normalize(lon12));      // L[31]: the radar's longitude, normalised
-    double lat = atan2d(sbet2, f1 * cbet2);
+    // lat = atan2(sbet2, f1 cbet2) as the radar's own latitude L[34] = atan2(L[35], L[36]) plus the small angle between
+    // the two directions (difference formula of the arc tangent), instead of a full-range atan2 per gate
+    const double fc2 = f1 * cbet2;
+    double lat = L[34] + atan2_small(sbet2 * L[36] - fc2 * L[35], fc2 * L[36] + sbet2 * L[35]) * RAD2DEG;
     out.lat = lat; out.lon = lon;
 
     // ---- rotated pole (north pole from the southern-pole metadata) ----
+    double sp = L[28], cp = L[29];
+    // lat = atan2(sbet2, f1 cbet2): its sine and cosine are that pair normalised
+    const double rh = rsqrt_fast(sbet2 * sbet2 + fc2 * fc2);
+    double sphi = sbet2 * rh, cphi = fc2 * rh, sdl, cdl;
+    // longitude difference to the rotated pole, formed as the reference forms it; its sine and cosine from those of
+    // the radar's own difference L[37] (L[32], L[33]) and the small angle in between, which the subtraction of the two
+    // nearby float64 values gives exactly
     double pollon = gp.pole_lon_s - 180.0;
     if (pollon < -180.0) pollon += 360.0;
-    double sp = L[28], cp = L[29];
-    double dl = (lon - pollon) * DEG;
-    // lat = atan2(sbet2, f1 cbet2): its sine and cosine are that pair normalised
-    const double fc2 = f1 * cbet2;
-    const double rh = 1. / sqrt(sbet2 * sbet2 + fc2 * fc2);
-    double sphi = sbet2 * rh, cphi = fc2 * rh, sdl, cdl;
-    sincos(dl, &sdl, &cdl);
+    const double dl = (lon - pollon) * DEG, ddl = dl - L[37];
+    if (fabs(ddl) < SMALL_ANGLE) {
+        double sl, cl;
+        sincos_small(ddl, &sl, &cl);
+        sdl = L[32] * cl + L[33] * sl; cdl = L[33] * cl - L[32] * sl;
+    } else sincos(dl, &sdl, &cdl);
     double a0 = cp * cphi * cdl + sp * sphi;
     double a1 = -sdl * cphi;
     double a2 = -sp * cphi * cdl + cp * sphi;
-    double rlat = asin(a0) * RAD2DEG, rlon = atan2(a1, a2) * RAD2DEG;
+    double rlat = asin_small(a0) * RAD2DEG, rlon = atan2_small(a1, a2) * RAD2DEG;
     out.rlat = (float)rlat;
     out.rlon = (float)rlon;
     // domain check of interpolation.py:359-362 (float64 coordinates against float32 corners)
@@ -931,6 +975,102 @@ __device__ inline float psd_cutoff_x(float l2, float cut_e = 152.f)
     return (l2 > 0.f && l2 < __builtin_inff()) ? cut_e / l2 : __builtin_inff();
 }
 
+// ---- float64 log2 / exp2 for the PSD set-up -----------------------------------------------------------------
+// The consumers of the PSD parameters are a float32 pair hi + lo of lambda log2(e) (exponent arguments exact to one
+// float32 rounding need it to 2^-40) and coefficients that end in float32 results (1e-9 is plenty).  The library
+// routines are correct to an ulp of float64 and pay for it with extended-precision arithmetic; these two stay
+// below 2^-44 relative (log2: absolute, on a result of order one or more) with plain float64 operations:
+//   log2_psd: x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), log2 m = (2 / ln 2) s (1 + s^2/3 + ... + s^16/17);
+//             |s| <= 0.1716, the first term left out is s^18 / 19 < 9e-16 of the leading one.
+//             0 -> -inf, +inf -> +inf, negative or NaN -> NaN.
+//   exp2_psd: y = n + f, |f| <= 1/2, 2^f by the Taylor polynomial of degree 12 in f ln 2 (next term (0.3466)^13 / 13!
+//             = 1.7e-16), scaled by v_ldexp_f64, which rounds into the subnormal range and overflows to inf like
+//             the library routine.  -inf -> 0, +inf -> inf, NaN -> NaN.
+__device__ inline double rcp_psd(double d)
+{   // 1 / d for a normal, finite d: hardware seed and two Newton steps
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.), r, r);
+    return r;
+}
+
+__device__ inline double log2_psd(double x)
+{
+    double m = __builtin_amdgcn_frexp_mant(x);          // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = (m - 1.) * rcp_psd(m + 1.);
+    const double z = s * s;
+    double p = 2.8853900817779268 / 17.;
+    p = __builtin_fma(p, z, 2.8853900817779268 / 15.);
+    p = __builtin_fma(p, z, 2.8853900817779268 / 13.);
+    p = __builtin_fma(p, z, 2.8853900817779268 / 11.);
+    p = __builtin_fma(p, z, 2.8853900817779268 / 9.);
+    p = __builtin_fma(p, z, 2.8853900817779268 / 7.);
+    p = __builtin_fma(p, z, 2.8853900817779268 / 5.);
+    p = __builtin_fma(p, z, 2.8853900817779268 / 3.);
+    p = __builtin_fma(p, z, 2.8853900817779268);
+    double r = __builtin_fma(s, p, (double)e);
+    r = x == 0. ? -__builtin_inf() : r;
+    r = x == __builtin_inf() ? x : r;
+    return x >= 0. ? r : __builtin_nan("");
+}
+
+__device__ inline double exp2_psd(double y)
+{
+    y = y < -1100. ? -1100. : y;                        // v_ldexp_f64 takes a 32-bit exponent: keep it small
+    y = y > 1100. ? 1100. : y;                          // (a NaN passes both tests and comes out as NaN)
+    const double n = __builtin_rint(y);
+    const double t = (y - n) * 0.69314718055994531;
+    double p = 1. / 479001600.;
+    p = __builtin_fma(p, t, 1. / 39916800.);
+    p = __builtin_fma(p, t, 1. / 3628800.);
+    p = __builtin_fma(p, t, 1. / 362880.);
+    p = __builtin_fma(p, t, 1. / 40320.);
+    p = __builtin_fma(p, t, 1. / 5040.);
+    p = __builtin_fma(p, t, 1. / 720.);
+    p = __builtin_fma(p, t, 1. / 120.);
+    p = __builtin_fma(p, t, 1. / 24.);
+    p = __builtin_fma(p, t, 1. / 6.);
+    p = __builtin_fma(p, t, 0.5);
+    p = __builtin_fma(p, t, 1.);
+    p = __builtin_fma(p, t, 1.);
+    return __builtin_ldexp(p, (int)n);
+}
+
+// The PSD of one class at one point as the integration kernels take it: l2 = lambda log2(e) and
+// nf = N0 2^(-l2 x0), the intercept with the factor of the reference abscissa x0 folded in (hydrometeors.py
+// set_psd; the branches of psd_params, in base 2, with the two exponentials of N0 and of the factor merged into
+// one).  Not usable content (a mass density that is zero, negative or NaN where the branch divides by it): NaN.
+__device__ inline void psd_fast(const PsdView &p, float q, float qn, float T, double x0, double *l2_out, double *nf_out)
+{
+    double l2, nf;
+    if (p.kind == 2) {
+        float xm = q * 1.0f / (qn + 1.1920929e-07f);
+        xm = fminf(fmaxf(xm, (float)p.x_min), (float)p.x_max);
+        const double L = (p.log2_lf + log2_psd((double)xm)) * p.c_exp;
+        l2 = exp2_psd(L + p.l2_const);
+        nf = p.cn_unit * (double)qn * exp2_psd(__builtin_fma(L, p.c_n_exp, -l2 * x0));
+    } else {
+        double n0 = p.n0_fixed, lq = p.log2_lf;
+        if (p.kind == 1) {
+            // float32 intercept as the reference forms it; the exponential through float64 so that subnormal float32
+            // results are kept, as glibc's expf keeps them
+            const float n0f = 13.5f * (565000.0f * (float)exp2_psd((double)(-0.107f * (T - 273.15f)) * 1.4426950408889634)) / 1000.f;
+            const float an0 = (float)p.a * n0f;
+            n0 = (double)n0f;
+            lq += log2_psd((double)an0);
+        }
+        const double L = (lq - log2_psd((double)q)) * p.c_exp;
+        l2 = exp2_psd(L + p.l2_const);
+        nf = n0 * exp2_psd(-l2 * x0);
+        if (!(q > 0.f)) { l2 = __builtin_nan(""); nf = l2; }
+    }
+    *l2_out = l2; *nf_out = nf;
+}
+
 // Position of the run of equal keys this lane belongs to inside its wave.
 __device__ inline void wave_run(int k, int lane, int *head_lane, int *len)
 {
@@ -1002,16 +1142,14 @@ __device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool 
             int ie = nearest_node(e, lv.e_min, lv.e_step, lv.n_e);
             int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
             k = (h * ct.ne_max + ie) * ct.nt_max + it;
-            double l, n0;
-            psd_params(p, q, qn, T, &l, &n0);
-            double l2 = l * 1.4426950408889634;            // exponent in base 2
-            float hi = (float)l2;
-            lam[(long)h * nu + u] = make_float2(hi, (float)(l2 - (double)hi));
             // the integration works with exp(-lambda (D^nu - D_0^nu)): the factor of the first diameter goes
             // into the float64 coefficients
-            const double f0 = exp2(-l2 * ct.pol_x0[h]);
-            coef[(long)h * nu + u] = n0 * (double)lv.dD * w * f0;
-            if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = n0 * f0;
+            double l2, nf;
+            psd_fast(p, q, qn, T, ct.pol_x0[h], &l2, &nf);
+            float hi = (float)l2;
+            lam[(long)h * nu + u] = make_float2(hi, (float)(l2 - (double)hi));
+            coef[(long)h * nu + u] = nf * (double)lv.dD * w;
+            if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = nf;
         }
         if (live) key[(long)h * nu + u] = (cpol_key_t)k;
         // position of the unit inside its (bucket, shard) counter: one atomic per run of equal keys
@@ -1030,13 +1168,12 @@ __device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool 
                 float qd = val(pd.q_var);
                 float qnd = pd.qn_var >= 0 ? val(pd.qn_var) : 0.f;
                 float Td = val(pd.t_var);
-                double l, n0;
-                psd_params(pd, qd, qnd, Td, &l, &n0);
-                if (qd == 0.f) l = __builtin_nan("");
-                double l2 = l * 1.4426950408889634;
+                double l2, nf;
+                psd_fast(pd, qd, qnd, Td, ct.dop_x0[h], &l2, &nf);      // k_integrate_dop works relative to the first diameter
+                if (qd == 0.f) { l2 = __builtin_nan(""); nf = l2; }
                 float hi = (float)l2;
                 lam[dslot] = make_float2(hi, (float)(l2 - (double)hi));
-                n0d[dslot] = n0 * exp2(-l2 * ct.dop_x0[h]);      // k_integrate_dop works relative to the first diameter
+                n0d[dslot] = nf;
             }
             // the Doppler units of a bucket are as many as its polarimetric ones and take the same ranks:
             // k_scan_shards and k_scatter reuse the polarimetric counters, no second round of atomics

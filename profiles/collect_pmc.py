@@ -4,7 +4,7 @@
 write per-kernel averages per launch to gpurun_out/<tag>_pmc.json and gpurun_out/traffic.json (copied into
 profiles/ afterwards: only gpurun_out/ travels back from the GPU box).
 
-    python3 profiles/collect_pmc.py <tag>            # on the GPU box, from the repository root
+    python3 profiles/collect_pmc.py <tag> [passes]   # on the GPU box, from the repository root; passes e.g. 0,1
 
 Every pass is its own short bench run (1 warm-up + 1 timed volume, no CPU baseline) under a hard time limit;
 the script stops at the first pass that fails.  HBM bytes: FETCH_SIZE and WRITE_SIZE are reported in KiB; on
@@ -62,7 +62,10 @@ def main():
     result = {"command": "rocprofv3 --pmc <group> --kernel-include-regex \"%s\" -- python3 bench.py --steps 1 --warmup 1 "
                          "--no-cpu-baseline --no-host-copy" % KERNELS,
               "note": "one pass per counter group; values are averages per launch", "kernels": {}}
+    only = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else range(len(PASSES))
     for i, group in enumerate(PASSES):
+        if i not in only:
+            continue
         print("pass %d: %s" % (i, " ".join(group)), flush=True)
         res = run_pass(group, os.path.join(ROOT, "gpurun_out", "pmc_pass%d" % i))
         for k, cs in res.items():
