@@ -419,12 +419,15 @@ void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *
 
 // Eight heights of every column, at levels (k (nz - 1)) / 7, k = 0..7: the model top, the terrain and six levels
 // in between, 32 bytes that start the level search of k_interp with one access instead of three bisection steps.
+// Order inside the record: top (k = 0), terrain (k = 7), then k = 1..6 - a neighbour column's top / terrain test
+// reads the first eight bytes.
 __global__ void k_coarse_levels(const float *__restrict__ zcol, float *__restrict__ zc8, int nz, long ncell)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncell * 8) return;
     const long c = t >> 3;
-    const int k = (int)(t & 7);
+    const int i = (int)(t & 7);
+    const int k = i == 0 ? 0 : i == 1 ? 7 : i - 1;
     zc8[t] = zcol[c * nz + (k * (nz - 1)) / 7];
 }
 
@@ -502,6 +505,8 @@ void launch_model_range(hipStream_t s, const float *dcol, size_t n_val, const fl
 #ifndef FRONT_OCC
 #define FRONT_OCC 6
 #endif
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // 16- and 8-byte loads at 4-byte alignment
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #define INTERP_XCD_RUN 72
 #define INTERP_REC 17
 #define INTERP_BATCH 4
@@ -539,11 +544,14 @@ __device__ inline int interp_point(const ModelView &mv, float (*__restrict__ s_r
         // top, terrain and six levels in between of the four columns
         const float4 *q = (const float4 *)(mv.zc8 + cell[0] * 8);
         const float4 q0 = q[0], q1 = q[1];
-        const float ck[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const float ck[8] = {q0.x, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q0.y};      // record order: top, terrain, k = 1..6
         float ztop[4], zbot[4];
         ztop[0] = ck[0]; zbot[0] = ck[7];
 #pragma unroll
-        for (int j = 1; j < 4; j++) { ztop[j] = mv.zc8[cell[j] * 8]; zbot[j] = mv.zc8[cell[j] * 8 + 7]; }
+        for (int j = 1; j < 4; j++) {
+            const float2 tb = *(const float2 *)(mv.zc8 + cell[j] * 8);
+            ztop[j] = tb.x; zbot[j] = tb.y;
+        }
         const float t0 = zbot[0], t1 = zbot[1], t2 = zbot[2], t3 = zbot[3];
         float topo = dx * dy * t0 + x * t2 * dy + dx * t1 * y + x * y * t3;
         if (!(topo < H)) code = 1;
@@ -597,30 +605,18 @@ __device__ inline int interp_point(const ModelView &mv, float (*__restrict__ s_r
                     cnt[0] = kk < 8 ? lo : nz;
                 }
                 bool redo[4] = {false, false, false, false};
-                {
-                    const int lo = cnt[0] - 2;
-                    float w[3][4];
-#pragma unroll
-                    for (int j = 1; j < 4; j++)
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int idx = min(max(lo + k, 0), nz - 1);
-                            w[j - 1][k] = col[j][idx];
-                        }
+                if (nz >= 4) {
+                    // four consecutive levels of each neighbour around column 0's count, one 16-byte load per column
+                    // (4-byte aligned); on a descending column the count is exact when the level above the window is
+                    // not below H and the level below it is
+                    const int base = min(max(cnt[0] - 2, 0), nz - 4);
 #pragma unroll
                     for (int j = 1; j < 4; j++) {
-                        const bool lower_ok = lo <= 0 || w[j - 1][0] >= H;         // every level above the window is >= H
-                        const bool upper_ok = lo + 3 >= nz - 1 || w[j - 1][3] < H; // every level below it is < H
-                        int c = max(lo, 0);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int idx = lo + k;
-                            if (idx >= 0 && idx <= nz - 1 && w[j - 1][k] >= H) c++;
-                        }
-                        cnt[j] = c;
-                        redo[j] = !(lower_ok && upper_ok);
+                        const f32x4u wv = *(const f32x4u *)(col[j] + base);
+                        cnt[j] = base + (wv.x >= H ? 1 : 0) + (wv.y >= H ? 1 : 0) + (wv.z >= H ? 1 : 0) + (wv.w >= H ? 1 : 0);
+                        redo[j] = !((base == 0 || wv.x >= H) && (base + 3 == nz - 1 || wv.w < H));
                     }
-                }
+                } else redo[1] = redo[2] = redo[3] = true;
                 if (redo[1] || redo[2] || redo[3]) {
                     int c2[4] = {0, 0, 0, 0};
                     for (int step = 1 << (31 - __clz(nz)); step > 0; step >>= 1) {
@@ -657,8 +653,8 @@ __device__ inline int interp_point(const ModelView &mv, float (*__restrict__ s_r
         float fzj = 1.f, hzj = 0.f;
         int basej = 0;
         if (code == 0) {
-            const float *zc = mv.zcol + cell[j] * nz + c1[j];
-            float za = zc[0], zb = zc[1];
+            const f32x2u zp = *(const f32x2u *)(mv.zcol + cell[j] * nz + c1[j]);      // the pair in one 8-byte load
+            const float za = zp.x, zb = zp.y;
             fzj = za - zb;
             hzj = H - zb;
             basej = (int)((cell[j] * nz + c1[j]) * (mv.nvp >> 2));    // offset of the level pair in 16-byte words (< 2^31)
@@ -1137,6 +1133,10 @@ __device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool 
         float q = val(p.q_var);
         float qn = p.qn_var >= 0 ? val(p.qn_var) : 0.f;
         bool valid = live && (q > 0.f);
+        if (__builtin_amdgcn_ballot_w64(valid) == 0) {               // no unit of this class in the whole wavefront
+            if (live) key[(long)h * nu + u] = (cpol_key_t)-1;
+            continue;
+        }
         int k = -1;
         if (valid) {
             int ie = nearest_node(e, lv.e_min, lv.e_step, lv.n_e);
@@ -1228,7 +1228,20 @@ void k_front(GeomParams gp, ModelView mv, ClassTable ct, long nu, const double *
     const long rb = uu / gp.n_gates;
     const int b = (int)(rb % gp.n_sub);
     GeoPoint p;
-    geom_point(gp, mv, line + rb * LINE_N, g, p);
+    double w_sub;
+    {
+        // The 64 positions of a wavefront nearly always lie on one (ray, sub-beam) line: its record (and the sub-beam's
+        // weight) is then read through a wave-uniform pointer, i.e. by scalar loads that bypass the vector memory
+        // path, which this kernel keeps as busy as its vector ALUs.
+        const int rb_first = __builtin_amdgcn_readfirstlane((int)rb);
+        if (__builtin_amdgcn_ballot_w64(rb != (long)rb_first) == 0) {
+            geom_point(gp, mv, line + (long)rb_first * LINE_N, g, p);
+            w_sub = wsub[rb_first % gp.n_sub];
+        } else {
+            geom_point(gp, mv, line + rb * LINE_N, g, p);
+            w_sub = wsub[b];
+        }
+    }
     if (live) {
         fo.E[u] = p.E;
         if (p.outside) fo.status[(int)(rb / gp.n_sub)] = CPOL_ERR_DOMAIN;
@@ -1251,7 +1264,7 @@ void k_front(GeomParams gp, ModelView mv, ClassTable ct, long nu, const double *
         }
     }
     auto val = [&](int v) { return code == 0 ? rec[mv.slot_of_var[v]] : qnan; };
-    prep_classes(ct, nu, u, live, lane, val(CPOL_V_T), p.E, wsub[b], doppler, val, fo.key, fo.rank, fo.lam, fo.coef,
+    prep_classes(ct, nu, u, live, lane, val(CPOL_V_T), p.E, w_sub, doppler, val, fo.key, fo.rank, fo.lam, fo.coef,
                  fo.n0d, fo.hist);
 }
 
@@ -1367,23 +1380,25 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 }
 
 // Final position of every valid polarimetric unit = bucket start + start of its shard inside the bucket + the
-// rank k_prep drew.
-__global__ void k_scatter(long nu, const cpol_key_t *__restrict__ key, const int *__restrict__ rank,
+// rank the PSD set-up drew.  One thread per position, its (up to four) classes one after the other.
+__global__ void k_scatter(long nu, int n_cls, const cpol_key_t *__restrict__ key, const int *__restrict__ rank,
                           const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
-    const int pl = blockIdx.y;                 // polarimetric planes only: the separate Doppler units follow their twins
-    const long slot = (long)pl * nu + u;
-    const int k = key[slot];
-    if (k < 0) return;
-    sorted[offs[k] + cursor[k * CPOL_SORT_SHARDS + (int)((u >> 8) & (CPOL_SORT_SHARDS - 1))] + rank[slot]] = (int)slot;
+    const int shard = (int)((u >> 8) & (CPOL_SORT_SHARDS - 1));
+    int k[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) k[h] = h < n_cls ? key[(long)h * nu + u] : -1;
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+        if (k[h] >= 0) sorted[offs[k[h]] + cursor[k[h] * CPOL_SORT_SHARDS + shard] + rank[(long)h * nu + u]] = (int)((long)h * nu + u);
 }
 
 void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
                     const int *cursor, int *sorted)
 {
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256), n_cls), dim3(256), 0, s, nu, key, rank, offs, cursor,
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, nu, n_cls, key, rank, offs, cursor,
                        sorted);
 }
 
