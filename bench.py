@@ -516,6 +516,7 @@ def main(argv=None):
                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                         'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
                         'launches': tim['launches']['integrate'], 'evaluated_fraction': evaluated,
+                        'own_quads_fraction': (tim['own_unit_diameters'] / (1024. * tim['valid_units']) if tim['valid_units'] else None),
                         'algorithmic_tflops': algorithmic}
             stage = {k: v / args.steps for k, v in tim['ms'].items()}
             stage['ms_per_step_with_stage_timing'] = dt_instr / args.steps * 1e3

@@ -88,7 +88,7 @@ def load():
     lib.cpol_synchronize.argtypes = [vp]
     lib.cpol_timing_enable.argtypes = [vp, C.c_int]
     lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
-    lib.cpol_timing_work.argtypes = [vp, c_double_p, c_double_p]
+    lib.cpol_timing_work.argtypes = [vp, c_double_p, c_double_p, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_host_batching.argtypes = [vp, C.c_int, C.c_double]
     lib.cpol_set_term_cutoff.argtypes = [vp, C.c_int]
@@ -189,11 +189,11 @@ class Context(object):
         nl = (C.c_long * len(self.STAGES))()
         vu, du = C.c_double(), C.c_double()
         self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu), C.byref(du)), 'cpol_timing_read')
-        wk, wd = C.c_double(), C.c_double()
-        self._check(self.lib.cpol_timing_work(self.h, C.byref(wk), C.byref(wd)), 'cpol_timing_work')
+        wk, wd, wo = C.c_double(), C.c_double(), C.c_double()
+        self._check(self.lib.cpol_timing_work(self.h, C.byref(wk), C.byref(wd), C.byref(wo)), 'cpol_timing_work')
         return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
                 'valid_units': vu.value, 'doppler_units': du.value, 'evaluated_unit_diameters': wk.value,
-                'doppler_unit_diameters': wd.value}
+                'doppler_unit_diameters': wd.value, 'own_unit_diameters': wo.value}
 
     def set_term_cutoff(self, certified=True):
         self._check(self.lib.cpol_set_term_cutoff(self.h, int(bool(certified))), 'cpol_set_term_cutoff')

@@ -92,7 +92,7 @@ extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     timing_collect(ctx);
-    const size_t work_bytes = 2 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE * sizeof(unsigned long long);
+    const size_t work_bytes = 3 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE * sizeof(unsigned long long);
     if (on && !ctx->work_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->work_dev, work_bytes));
     if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, work_bytes));
     ctx->timing = on != 0;
@@ -117,23 +117,24 @@ extern "C" int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], l
     return CPOL_OK;
 }
 
-extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters)
+extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters,
+                                double *own_unit_diameters)
 {
     if (!ctx || !evaluated_unit_diameters) return CPOL_ERR_ARG;
     *evaluated_unit_diameters = 0.;
     if (doppler_unit_diameters) *doppler_unit_diameters = 0.;
+    if (own_unit_diameters) *own_unit_diameters = 0.;
     if (!ctx->work_dev) return CPOL_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<unsigned long long> w(2 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE);
+    std::vector<unsigned long long> w(3 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE);
     HIPCHK(ctx, hipMemcpy(w.data(), ctx->work_dev, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double tot = 0., totd = 0.;
-    for (int i = 0; i < CPOL_WORK_SLOTS; i++) {
-        tot += (double)w[(size_t)i * CPOL_WORK_STRIDE];
-        totd += (double)w[(size_t)(CPOL_WORK_SLOTS + i) * CPOL_WORK_STRIDE];
-    }
-    *evaluated_unit_diameters = 16. * tot;
-    if (doppler_unit_diameters) *doppler_unit_diameters = 16. * totd;
+    double tot[3] = {0., 0., 0.};
+    for (int k = 0; k < 3; k++)
+        for (int i = 0; i < CPOL_WORK_SLOTS; i++) tot[k] += (double)w[(size_t)(k * CPOL_WORK_SLOTS + i) * CPOL_WORK_STRIDE];
+    *evaluated_unit_diameters = 16. * tot[0];
+    if (doppler_unit_diameters) *doppler_unit_diameters = 16. * tot[1];
+    if (own_unit_diameters) *own_unit_diameters = 16. * tot[2];
     return CPOL_OK;
 }
 

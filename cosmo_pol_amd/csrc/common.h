@@ -168,7 +168,7 @@ struct cpol_ctx {
     // optional stage timing (hipEvents on ctx->stream) and work counters
     bool   certified_cutoff = true;               // term cutoffs below the exact-zero one where the tables carry a certificate
     float *cert_dev = nullptr;                    // result word of k_cut_certificate
-    unsigned long long *work_dev = nullptr;       // 2 x 64 partial counts of unit x 16-diameter steps evaluated by k_integrate / k_integrate_dop (timing only)
+    unsigned long long *work_dev = nullptr;       // 3 x CPOL_WORK_SLOTS partial counts of unit x 16-diameter steps: evaluated by k_integrate, by k_integrate_dop, and the units' own counts in k_integrate (timing only)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;

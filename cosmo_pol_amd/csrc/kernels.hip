@@ -805,59 +805,86 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 }
 
 // Certificate for a term cutoff below the exact-zero one.  A unit with slope l2 leaves out the quads whose first
-// D^nu - x_ref exceeds cut_e / l2.  For every table node, every column and every quad boundary c = 16 (q + 1) the
-// kernel evaluates the worst case of the units that stop there - l2 = cut_e / x_c, the smallest slope with that
-// cutoff, for which the omitted terms weigh most - and forms
-//     sum_{d >= c} |B'[d][j]| 2^(-l2 x_d)  /  sum_d |B'[d][j]| 2^(-l2 x_d)
-// (within one cutoff interval the omitted terms decay faster with l2 than the kept ones, so the left end is the
-// supremum).  The maximum over nodes, columns and boundaries goes to *worst; the host accepts cut_e when it is
-// below 2^-28, a sixteenth of float32's resolution of the sum.
+// D^nu - x_ref exceeds cut_e / l2, so the units that stop at the quad boundary c = 16 (q + 1) have slopes in
+// (cut_e / x_c, cut_e / x_{c-16}].  The observables are made of linear combinations of the twelve columns
+// (scattering_sz.py:168-194), and a difference of two nearly equal columns can lose far more of itself to an
+// omitted tail than either column does, so the certificate is about those combinations:
+//     h = s0 - s1 - s2 + s3 (ZH, ZDR, RHOHV), v = s0 + s1 + s2 + s3 (ZV, ZDR, RHOHV), k = s10 - s8 (KDP),
+//     s11 (AH), s9 (AV), the complex number (s4 + s7) + i (s6 - s5) whose modulus enters RHOHV and whose
+//     argument is DELTA_HV, and the two Doppler scheme-2 moments.
+// For every table node, every boundary, CERT_SAMPLES slopes spread over the boundary's interval and every such
+// quantity g the kernel forms
+//     sum_{d >= c} |g_d| 2^(-l2 x_d)  /  | sum_d g_d 2^(-l2 x_d) |
+// - the omitted terms at their worst (all of one sign) against the signed value the unit contributes; the two parts
+// of the complex number are both measured against its modulus, the scale RHOHV and DELTA_HV see them at.  The
+// maximum over everything goes to *worst; the host accepts cut_e when it is below 2^-28, a sixteenth of float32's
+// resolution.  A combination that changes sign along the diameter axis can have a unit value near zero at some
+// slope; the ratio is then large and the class keeps the exact-zero rule, which is always safe.
+#define CERT_SAMPLES 4
+#define CERT_NG 9
 __global__ __launch_bounds__(256)
 void k_cut_certificate(const float *__restrict__ raw, const float *__restrict__ d_axis, double mu, double nu, double x_ref,
                        int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, unsigned *__restrict__ worst)
 {
-    constexpr int NJ = 14;
-    __shared__ double s_red[4][2 * NJ];
+    constexpr int NG = CERT_NG;
+    __shared__ double s_red[4][2 * NG];
     const long sl = blockIdx.x;
     const int c = 16 * ((int)blockIdx.y + 1);
     const double xc = pow((double)d_axis[c], nu) - x_ref;
     if (!(xc > 0.)) return;
-    const double l2 = cut_e / xc;
-    double tot[NJ], tail[NJ];
+    // slopes of the boundary's interval, from the smallest (the omitted terms weigh most) towards the largest; the
+    // first boundary's interval has no upper end and is sampled up to eight times its lower one
+    const double x_prev = pow((double)d_axis[c - 16], nu) - x_ref;
+    const double span = (c > 16 && x_prev > 0.) ? xc / x_prev : 8.;
+    const double l2 = cut_e / xc * pow(span, (double)blockIdx.z / CERT_SAMPLES);
+    double tot[NG], tail[NG];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { tot[j] = 0.; tail[j] = 0.; }
+    for (int j = 0; j < NG; j++) { tot[j] = 0.; tail[j] = 0.; }
     for (int d = threadIdx.x; d < 1024; d += 256) {
         const double D = (double)d_axis[d];
         const double n = exp2(-l2 * (pow(D, nu) - x_ref));
         const double dm = pow(D, mu) * n;
         const float *src = raw + (sl * 1024 + d) * CPOL_N_SZ;
-        double w[NJ];
+        double z[CPOL_N_SZ], g[NG];
 #pragma unroll
-        for (int j = 0; j < CPOL_N_SZ; j++) w[j] = fabs((double)src[j]) * dm;
-        w[12] = 0.; w[13] = 0.;
+        for (int j = 0; j < CPOL_N_SZ; j++) z[j] = (double)src[j] * dm;
+        g[0] = ((z[0] - z[1]) - z[2]) + z[3];
+        g[1] = ((z[0] + z[1]) + z[2]) + z[3];
+        g[2] = z[10] - z[8];
+        g[3] = z[4] + z[7];
+        g[4] = z[6] - z[5];
+        g[5] = z[9];
+        g[6] = z[11];
+        g[7] = 0.; g[8] = 0.;
         if (with_dop) {
-            const double rcs = fabs(2 * M_PI * ((((double)src[0] - src[1]) - src[2]) + src[3])) * pow(D, mu_d) * n;
-            w[12] = rcs; w[13] = rcs * alpha_d * pow(D, beta_d);
+            const double rcs = 2 * M_PI * ((((double)src[0] - src[1]) - src[2]) + src[3]) * pow(D, mu_d) * n;
+            g[7] = rcs; g[8] = rcs * alpha_d * pow(D, beta_d);
         }
 #pragma unroll
-        for (int j = 0; j < NJ; j++) { tot[j] += w[j]; if (d >= c) tail[j] += w[j]; }
+        for (int j = 0; j < NG; j++) { tot[j] += g[j]; if (d >= c) tail[j] += fabs(g[j]); }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
+    for (int j = 0; j < NG; j++) {
         for (int off = 32; off > 0; off >>= 1) { tot[j] += __shfl_xor(tot[j], off); tail[j] += __shfl_xor(tail[j], off); }
-        if (lane == 0) { s_red[wv][j] = tot[j]; s_red[wv][NJ + j] = tail[j]; }
+        if (lane == 0) { s_red[wv][j] = tot[j]; s_red[wv][NG + j] = tail[j]; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double r = 0.;
-        for (int j = 0; j < NJ; j++) {
-            const double t = s_red[0][j] + s_red[1][j] + s_red[2][j] + s_red[3][j];
-            const double tl = s_red[0][NJ + j] + s_red[1][NJ + j] + s_red[2][NJ + j] + s_red[3][NJ + j];
-            if (t > 0.) r = fmax(r, tl / t);
-            else if (tl > 0. || t != t) r = 1.;          // nothing kept, or not a number: no certificate
+        double t[NG], tl[NG];
+        for (int j = 0; j < NG; j++) {
+            t[j] = fabs(s_red[0][j] + s_red[1][j] + s_red[2][j] + s_red[3][j]);
+            tl[j] = s_red[0][NG + j] + s_red[1][NG + j] + s_red[2][NG + j] + s_red[3][NG + j];
         }
-        const float rf = (float)(r * 1.000001);           // rounded up; non-negative floats order like their bit patterns
+        t[3] = t[4] = hypot(t[3], t[4]);                   // both parts against the modulus
+        double r = 0.;
+        for (int j = 0; j < NG; j++) {
+            if (tl[j] == 0.) continue;                     // nothing omitted (an all-zero combination)
+            if (t[j] > 0.) r = fmax(r, tl[j] / t[j]);
+            else r = 1.;                                   // nothing kept: no certificate
+            if (tl[j] != tl[j] || t[j] != t[j]) r = 1.;    // not a number: no certificate
+        }
+        const float rf = (float)fmin(r * 1.000001, 1.);   // rounded up; non-negative floats order like their bit patterns
         atomicMax(worst, __float_as_uint(rf));
     }
 }
@@ -866,8 +893,8 @@ float cut_certificate(hipStream_t s, const float *raw, const float *d_axis, long
                       int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, float *worst_dev)
 {
     if (hipMemsetAsync(worst_dev, 0, sizeof(float), s) != hipSuccess) return 1.f;
-    hipLaunchKernelGGL(k_cut_certificate, dim3((unsigned)nslice, 63), dim3(256), 0, s, raw, d_axis, mu, nu, x_ref, with_dop,
-                       mu_d, alpha_d, beta_d, cut_e, (unsigned *)worst_dev);
+    hipLaunchKernelGGL(k_cut_certificate, dim3((unsigned)nslice, 63, CERT_SAMPLES), dim3(256), 0, s, raw, d_axis, mu, nu, x_ref,
+                       with_dop, mu_d, alpha_d, beta_d, cut_e, (unsigned *)worst_dev);
     float w = 1.f;
     if (hipMemcpyAsync(&w, worst_dev, sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess) return 1.f;
     if (hipStreamSynchronize(s) != hipSuccess) return 1.f;
@@ -1555,7 +1582,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int bbase = j < NC ? kq * NC + j : (LDS_ZERO + ((kq * NC * 4 + NC * 4) & 63)) / 4;
     const int bstride = j < NC ? 4 * NC : 0;
     const int npass = (cnt + 31) >> 5;
-    unsigned wsum = 0;
+    unsigned wsum = 0, own = 0;
 
     // passes of 32 units in cutoff order; the waves take them in snake order (0 1 2 ... 7 7 6 ... 0 ...) so
     // that every wave gets cheap and expensive ones
@@ -1583,6 +1610,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         const int nq = __shfl(ulast >= g0 * 16 + 16 ? nqb : nqa, ulast & 15);
         const int nq_lo = __shfl(nqa, 0);
         wsum += (unsigned)nq * (unsigned)min(cnt - g0 * 16, 32);
+        if (kq == 0) own += (unsigned)((ua < cnt ? nqa : 0) + (ub < cnt ? nqb : 0));      // the units' own quad counts
         if (gstep > 0.f) {
             // nu = 1 on a uniform diameter axis: N(D) is a geometric sequence.  A lane's four values of a quad
             // are 4 diameters apart (ratio R per unit), the same lane's values of the next quad 16 further
@@ -1699,7 +1727,12 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         }
     }
     if (work) {                                       // wave-uniform count of evaluated unit x quad steps
-        if (lane == 0) atomicAdd(&work[((blockIdx.x * NW + wave) & (CPOL_WORK_SLOTS - 1)) * CPOL_WORK_STRIDE], (unsigned long long)wsum);
+        for (int off = 32; off > 0; off >>= 1) own += __shfl_xor(own, off);
+        const int slot = ((blockIdx.x * NW + wave) & (CPOL_WORK_SLOTS - 1)) * CPOL_WORK_STRIDE;
+        if (lane == 0) {
+            atomicAdd(&work[slot], (unsigned long long)wsum);
+            atomicAdd(&work[2 * CPOL_WORK_SLOTS * CPOL_WORK_STRIDE + slot], (unsigned long long)own);
+        }
     }
 }
 

@@ -125,8 +125,11 @@ int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_l
  * that diameter inside their bucket and a wavefront stops at the last 16-diameter step any of its units
  * still needs, so this is less than 1024 x valid_units (no counterpart in the reference, which evaluates
  * all 1024 terms in float64, scattering_sz.py:95-103).  doppler_unit_diameters (may be NULL): the same for
- * stage INTEGRATE_DOP, where a unit whose N0 is an exact zero needs no term at all. */
-int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters);
+ * stage INTEGRATE_DOP, where a unit whose N0 is an exact zero needs no term at all.  own_unit_diameters (may be
+ * NULL): the terms up to each unit's own stopping point, i.e. what stage INTEGRATE would evaluate if no unit had to
+ * run on to the stopping point of the last unit of its group of 32. */
+int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters,
+                     double *own_unit_diameters);
 /* Which terms of the PSD integration (scattering_sz.py:95-103: all 1024 diameters, float64) are evaluated.  The
  * terms whose N(D) = exp(-lambda D^nu) underflows to an exact float32 zero are always left out.  With
  * certified != 0 (the default) a class may stop earlier, at N(D) < 2^-E N(D_0), E in {48 .. 128}: when its tables

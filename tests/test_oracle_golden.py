@@ -178,3 +178,28 @@ def test_turbulence_spread_definition():
     from scipy.ndimage import gaussian_filter1d
     f = gaussian_filter1d(spec[0], std[0] / (v[2] - v[1]))
     np.testing.assert_allclose(out[0], f / f.sum() * spec[0].sum(), rtol=1e-14)
+
+
+def test_numpy_float32_power_vs_correctly_rounded():
+    """The attenuation factors 10 ** (-0.1 A res_km) (scattering_sz.py:120-123) are float32 powers.  The HIP path takes
+    the correctly rounded float32 value (float64 evaluation, one rounding); NumPy's float32 power may be vectorised
+    and then is not correctly rounded.  Checked here, on whatever CPU runs the test, over a million arguments of the
+    attenuation range: NumPy's value never differs from the correctly rounded one by more than one float32 ulp, and
+    differs for at most a quarter of the arguments - which is what the long-ray parity test builds its bound on
+    (one ulp per differing factor).  The measured share is printed (0 where NumPy's power is correctly rounded)."""
+    rng = np.random.default_rng(1)
+    a = (10. ** rng.uniform(-6, 1.5, 1_000_000)).astype(np.float32)        # specific attenuation, dB / km
+    for res_km in (np.float32(0.075), np.float32(0.5)):
+        x = -0.1 * a * res_km
+        assert x.dtype == np.float32
+        got = 10 ** x                                                        # the reference's expression
+        assert got.dtype == np.float32
+        want = O.pow10_rounded(x)
+        # float64 pow is within an ulp of float64: its float32 rounding is the correctly rounded value except for
+        # results within 2^-29 of a rounding boundary
+        ulps = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32))
+        share = float((ulps != 0).mean())
+        print('res %.3f km: NumPy float32 10**x differs from the correctly rounded value for %.1f %% of %d arguments, '
+              'by %d ulp at most' % (float(res_km), 100 * share, x.size, int(ulps.max())))
+        assert ulps.max() <= 1
+        assert share <= 0.25
