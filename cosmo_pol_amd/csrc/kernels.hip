@@ -1576,11 +1576,28 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const int kq = lane >> 4, j = lane & 15;
     const float4 *B4 = (const float4 *)lds;
     const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
-    // float4 index of this lane's operand word: quad q -> bbase + q * bstride; the lanes of the
-    // four spare columns read a zero word
-    // (the zero word of a 16-lane group sits in the banks its NC real words leave free)
-    const int bbase = j < NC ? kq * NC + j : (LDS_ZERO + ((kq * NC * 4 + NC * 4) & 63)) / 4;
-    const int bstride = j < NC ? 4 * NC : 0;
+    // float4 index of this lane's operand word: quad q -> bbase + q * bstride.  Which of the 16 lanes of a row
+    // (k = kq) carries which column matters for the LDS: a ds_read_b128 is served in four groups of 16 lanes -
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same 32 lanes up - each conflict-free when its 16 words fall
+    // into 16 different quarters of the 64 banks.  A group is half of one row and the other half of the next, 12
+    // words further on, so with NC = 12 the columns are dealt to the lanes such that the two halves of a row hold
+    // complementary residues: lanes {0-3, 12, 13} take columns 0 4 8 1 5 9, lanes {4-9} columns 2 6 10 3 7 11, and the
+    // spare lanes {14, 15} and {10, 11} read a zero word in a quarter their group leaves free.
+    int comp = j, bbase, bstride;
+    if constexpr (NC == 12) {
+        const int half = (j >= 4 && j < 12) ? 1 : 0;
+        const int jj = half ? j - 4 : (j < 4 ? j : j - 8);           // 0..7 inside the half, 6 and 7 spare
+        const bool real = jj < 6;
+        comp = real ? (jj % 3) * 4 + jj / 3 + 2 * half : 12 + 2 * half + (jj - 6);
+        const int grp = 2 * (kq >> 1) + ((kq & 1) ^ half);
+        const int zero_quarter = grp == 0 ? 12 : grp == 1 ? 8 : grp == 2 ? 2 : 0;
+        bbase = real ? kq * NC + comp : LDS_ZERO / 4 + zero_quarter;
+        bstride = real ? 4 * NC : 0;
+    } else {
+        // (the zero word of a 16-lane group sits in the banks its NC real words leave free)
+        bbase = j < NC ? kq * NC + j : (LDS_ZERO + ((kq * NC * 4 + NC * 4) & 63)) / 4;
+        bstride = j < NC ? 4 * NC : 0;
+    }
     const int npass = (cnt + 31) >> 5;
     unsigned wsum = 0, own = 0;
 
@@ -1592,7 +1609,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         if (ps >= npass) continue;
         const int g0 = ps * 2;
         // two groups of 16 units per pass: two independent accumulators, and the two units'
-        // exponent arguments are formed together with packed f32 arithmetic
+        // exponent arguments are formed side by side
         int ua = g0 * 16 + j, ub = ua + 16;
         // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -1673,14 +1690,32 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
                 const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
                 // all eight N(D) values of the quad first (independent registers), then the
-                // eight MFMAs back to back: no MFMA waits for a transcendental result
+                // eight MFMAs back to back: no MFMA waits for a transcendental result.
+                // Exponent argument -(hi + lo) x: the hi part by one fused multiply-add per value, the lo part (2^-24 of
+                // it) with the quad's middle abscissa instead of x itself - the difference, lo (x - x_mid), is below
+                // the rounding of the argument at the quad's far end.  Plain float32 instructions in one block: beside
+                // the matrix instructions a packed v_pk_mul_f32 + v_pk_fma_f32 pair for both units costs more issue
+                // time than the separate instructions (measured), and the compiler would pack them again.
                 float na[4], nb_[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) {
-                    const f32x2 x2 = {xx[s4], xx[s4]};
-                    f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);   // one rounding of -(hi+lo)*x
-                    na[s4] = __builtin_amdgcn_exp2f(p.x);
-                    nb_[s4] = __builtin_amdgcn_exp2f(p.y);
+                {
+                    float ta, tb, p0, p1, p2, p3, p4, p5, p6, p7;
+                    asm volatile("v_mul_f32 %0, %12, %16\n\t"
+                                 "v_mul_f32 %1, %13, %16\n\t"
+                                 "v_fma_f32 %2, %10, %14, %0\n\t"
+                                 "v_fma_f32 %3, %11, %14, %1\n\t"
+                                 "v_fma_f32 %4, %10, %15, %0\n\t"
+                                 "v_fma_f32 %5, %11, %15, %1\n\t"
+                                 "v_fma_f32 %6, %10, %16, %0\n\t"
+                                 "v_fma_f32 %7, %11, %16, %1\n\t"
+                                 "v_fma_f32 %8, %10, %17, %0\n\t"
+                                 "v_fma_f32 %9, %11, %17, %1"
+                                 : "=&v"(ta), "=&v"(tb), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5),
+                                   "=&v"(p6), "=&v"(p7)
+                                 : "v"(nhi.x), "v"(nhi.y), "v"(nlo.x), "v"(nlo.y), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
+                    na[0] = __builtin_amdgcn_exp2f(p0); nb_[0] = __builtin_amdgcn_exp2f(p1);
+                    na[1] = __builtin_amdgcn_exp2f(p2); nb_[1] = __builtin_amdgcn_exp2f(p3);
+                    na[2] = __builtin_amdgcn_exp2f(p4); nb_[2] = __builtin_amdgcn_exp2f(p5);
+                    na[3] = __builtin_amdgcn_exp2f(p6); nb_[3] = __builtin_amdgcn_exp2f(p7);
                 }
                 if (tail) {
 #pragma unroll
@@ -1721,8 +1756,8 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 // result rows of 16 floats (the spare columns hold zeros): one aligned 64-byte write per unit,
                 // wherever the cutoff order scattered the pass's units over the slots
                 constexpr int ROW = CPOL_N_COL;
-                if (u0 < cnt) psd_out[(long)__float_as_int(urec[start + u0].w) * ROW + j] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)__float_as_int(urec[start + u1].w) * ROW + j] = (float)db[r];
+                if (u0 < cnt) psd_out[(long)__float_as_int(urec[start + u0].w) * ROW + comp] = (float)da[r];
+                if (u1 < cnt) psd_out[(long)__float_as_int(urec[start + u1].w) * ROW + comp] = (float)db[r];
             }
         }
     }
