@@ -174,6 +174,23 @@ class GpuRunner(object):
             self.ctx.set_batch_units(batch_units)
         self.n_gates, self.n_sub, self.n_vel = self.eng.n_gates, self.ctx.n_sub, self.ctx.n_vel
         self.doppler = self.ctx.doppler
+        # the library's own stream as a torch stream: torch work (packing, collectives) can be queued behind the kernels
+        self.lib_stream = torch.cuda.ExternalStream(self.ctx.stream, device=self.dev)
+        self.spans = []
+
+    def timed_run(self, az_t, el_t, out_struct):
+        """run() between two events on the library's stream (no host synchronisation)."""
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        e0.record(self.lib_stream)
+        self.run(az_t, el_t, out_struct)
+        e1.record(self.lib_stream)
+        self.spans.append((e0, e1))
+
+    def compute_ms(self):
+        """Sum of the timed_run spans so far (call after a synchronisation); clears them."""
+        t = sum(a.elapsed_time(b) for a, b in self.spans)
+        self.spans = []
+        return t
 
     def outputs(self, R, pinned_host=False):
         torch, G = self.torch, self.n_gates
@@ -242,13 +259,27 @@ class StubRunner(object):
     def angles(self, az, el):
         return self.torch.tensor(az, dtype=self.torch.float64), self.torch.tensor(el, dtype=self.torch.float64)
 
+    lib_stream = None
+
+    def timed_run(self, az_t, el_t, t):
+        t0 = time.perf_counter()
+        self.run(az_t, el_t, t)
+        self._ms = getattr(self, '_ms', 0.) + (time.perf_counter() - t0) * 1e3
+
+    def compute_ms(self):
+        t, self._ms = getattr(self, '_ms', 0.), 0.
+        return t
+
     def run(self, az_t, el_t, t):
         g = self.torch.arange(self.n_gates, dtype=self.torch.float64)[None, :]
         base = az_t[:, None] * 10. + el_t[:, None] * 1000. + g
         for i in range(9):
             t['obs'][i] = (base + 0.5 * i).float()
         t['rvel'].copy_(base * 2.)
-        t['mask'].zero_()
+        # mean of nine sub-beam codes: sums of -5, 9 and 0 in turn along the ray
+        code = self.torch.tensor([0., -5., 9., 0.], dtype=self.torch.float64)[(self.torch.arange(self.n_gates) % 4)]
+        m = code[None, :] / 9. + 0 * base
+        t['mask'].copy_(self.torch.where((m >= 0) & (m < 1), self.torch.zeros_like(m), m))
         t['lat'].copy_(base + 0.25)
         t['lon'].copy_(base + 0.75)
         t['dist'].copy_((g + 0 * base).float())
@@ -287,6 +318,9 @@ def main(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-host-copy', action='store_true', help='skip the second measurement with the outputs delivered to host memory')
     ap.add_argument('--no-overlap', action='store_true', help='N > 1: wait for each gather before the next volume starts')
+    ap.add_argument('--rehearse-gather', action='store_true', help='N = 1: run the gather path in a one-rank RCCL group (rehearsal; result is not a scaling number)')
+    ap.add_argument('--gather', choices=['compact', 'full'], default='compact',
+                    help='N > 1: compact (default) sends the scan geometry once and the mask as integer codes, full sends all seven fields every volume')
     ap.add_argument('--doppler', type=int, choices=[0, 1, 2, 3], default=None,
                     help='doppler.scheme of the workload (3 = full Doppler spectrum, needs --microphysics 1)')
     ap.add_argument('--microphysics', type=int, choices=[1, 2], default=None,
@@ -345,6 +379,12 @@ def main(argv=None):
             dist.init_process_group('gloo')
     else:
         torch.cuda.set_device(local_rank)
+        if args.rehearse_gather and world == 1:
+            # one-GPU rehearsal of the multi-rank path: a group of one rank over RCCL, the gather issued all the same
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
+            parallel.SINGLE_RANK_COLLECTIVES = True
         if world > 1:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         runner = GpuRunner(conf, model, tabs, local_rank, args.batch_units)
@@ -355,14 +395,18 @@ def main(argv=None):
     mine = shards[rank]
     R = len(mine)
     az_t, el_t = runner.angles(azs[mine], elv[mine])
-    gather = strong and world > 1
+    gather = strong and (world > 1 or args.rehearse_gather)
     n_buf = 2 if gather and not args.no_overlap else 1
     bufs = [runner.outputs(R) for _ in range(n_buf)]
     structs = [runner.struct(b) for b in bufs]
-    gathers = [parallel.VolumeGather(shards, len(azs)) for _ in range(n_buf)] if gather else None
-    pending = [False] * n_buf
-    t_compute = t_gather = 0.
+    # what travels: everything with --gather full; by default the scan geometry (lat, lon, range, height) once per
+    # buffer set and the mask as the integer sum of its sub-beam codes - 45 instead of 76 bytes per gate
+    compact = args.gather == 'compact'
+    gathers = [parallel.VolumeGather(shards, len(azs), static=('lat', 'lon', 'dist', 'height') if compact else (),
+                                     mask_sub=runner.n_sub if compact else 0) for _ in range(n_buf)] if gather else None
+    t_wait = 0.
     volume = None
+    assemble_ev = []
 
     def fields_of(t):
         from collections import OrderedDict
@@ -371,37 +415,36 @@ def main(argv=None):
             f[k] = t[k]
         return f
 
-    def finish(i):
-        nonlocal t_gather, volume
-        if gather and pending[i]:
+    def take(i):
+        """Rank 0 waits until the volume of buffer set i is in place (the consumer's wait); the wait is timed."""
+        nonlocal t_wait
+        if gather:
             t0 = time.perf_counter()
-            v = gathers[i].finish()
-            if not args.stub_engine:
-                torch.cuda.synchronize()
-            t_gather += time.perf_counter() - t0
-            pending[i] = False
-            if v is not None:
-                volume = v
+            gathers[i].wait()
+            t_wait += time.perf_counter() - t0
 
     def step(k):
-        nonlocal t_compute
+        nonlocal volume
         i = k % n_buf
-        finish(i)                                  # the buffer's previous volume has left
-        t0 = time.perf_counter()
-        runner.run(az_t, el_t, structs[i])
+        take(i)                                    # the buffer set's previous volume has been consumed
+        runner.timed_run(az_t, el_t, structs[i])
         if gather:
-            runner.sync()
-            t_compute += time.perf_counter() - t0
-            gathers[i].start(fields_of(bufs[i]), async_op=not args.no_overlap)
-            pending[i] = True
+            # queued behind the kernels on the library's stream: packing, the collective, and on rank 0 the indexed
+            # copy into the volume on a side stream; the host waits for none of it here
+            gathers[i].start(fields_of(bufs[i]), async_op=not args.no_overlap, geometry_key='scan', stream=runner.lib_stream)
+            v = gathers[i].finish()
+            if v is not None:
+                volume = v
+                if gathers[i].assemble_ms_events:
+                    assemble_ev.append(gathers[i].assemble_ms_events)
             if args.no_overlap:
-                finish(i)
+                take(i)
 
     def sync_all():
         for i in range(n_buf):
-            finish(i)
+            take(i)
         runner.sync()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     for k in range(args.warmup):
@@ -409,19 +452,23 @@ def main(argv=None):
     sync_all()
     assert int(bufs[0]['ray_status'].abs().sum().item()) == 0, "a ray left the model domain"
     timed = not args.stub_engine
-    t_compute = t_gather = 0.
+    runner.compute_ms()
+    t_wait = 0.
+    assemble_ev = []
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     sync_all()
     dt = time.perf_counter() - t0
+    t_compute = runner.compute_ms() * 1e-3
+    t_gather = t_wait
+    t_assemble = sum(a.elapsed_time(b) for a, b in assemble_ev) * 1e-3
     # The same steps once more with the library's stage timing on (HIP events around every stage on the library's
     # stream, work counters): the per-stage and per-kernel figures come from this pass, `value` from the plain one
     # above (the events and the small device-to-host copies of the counters cost about 4 % of a step).
     tim = None
     if timed:
-        keep = (t_compute, t_gather)
         runner.ctx.timing_enable(True)
         sync_all()
         t1 = time.perf_counter()
@@ -431,19 +478,31 @@ def main(argv=None):
         dt_instr = time.perf_counter() - t1
         tim = runner.ctx.timing_read()
         runner.ctx.timing_enable(False)
-        t_compute, t_gather = keep
-    if world > 1:
+        runner.compute_ms()
+    per_rank = None
+    if world > 1 or gather:
         t = torch.tensor([dt, t_compute, t_gather], dtype=torch.float64, device=runner.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mine_ms = {'rank': rank, 'rays': R, 'compute_ms': t_compute / args.steps * 1e3, 'wait_ms': t_gather / args.steps * 1e3,
+                   'assemble_ms': t_assemble / args.steps * 1e3}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_ms)
         dt, t_compute, t_gather = (float(x) for x in t.tolist())
     last = bufs[(args.steps - 1) % n_buf] if args.steps else bufs[0]
     finite = float(torch.isfinite(last['obs'][0]).float().mean().item())
     finite_rvel = float(torch.isfinite(last['rvel']).float().mean().item()) if doppler else None
-    gathered_ok = None
+    gathered_ok = volume_sha1 = None
     if gather and rank == 0 and volume is not None:
-        # rank 0's own rays sit at their positions of the gathered volume
-        gathered_ok = bool(torch.equal(volume['rvel'][torch.as_tensor(mine, device=volume['rvel'].device)].nan_to_num(),
-                                       last['rvel'].nan_to_num())) and tuple(volume['obs'].shape) == (len(azs), 9, G)
+        import hashlib
+        # rank 0's own rays sit at their positions of the gathered volume, for every field
+        sel = torch.as_tensor(mine, device=volume['rvel'].device)
+        gathered_ok = tuple(volume['obs'].shape) == (len(azs), 9, G)
+        for k, v in fields_of(last).items():
+            gathered_ok = gathered_ok and bool(torch.equal(volume[k][sel].nan_to_num(), v.nan_to_num()))
+        h = hashlib.sha1()
+        for k in ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height'):
+            h.update(volume[k].contiguous().cpu().numpy().tobytes())
+        volume_sha1 = h.hexdigest()
 
     # second measurement at N = 1: the same steps with the outputs delivered to (pinned) host memory, the copy of
     # one batch of rays running beside the kernels of the next (batches shrinking geometrically, so that the last
@@ -550,11 +609,18 @@ def main(argv=None):
         if host:
             line.update(host)
         if gather:
+            # compute_ms: a rank's kernels for its share of the rays (HIP events, no communication in it - what the
+            # rank would need for that share on its own); wait_ms: host time a rank spends waiting for the volume
+            # of a buffer set to be in place before it reuses the set (the GPU works meanwhile: with two sets this
+            # is most of a step, it is not exposed time); assemble_ms: the indexed copy of the received rows into
+            # the volume on rank 0
             line.update({'compute_ms_per_step_max_rank': t_compute / args.steps * 1e3,
                          'gather_wait_ms_per_step_max_rank': t_gather / args.steps * 1e3,
-                         'gather_overlapped': not args.no_overlap, 'gathered_volume_ok': gathered_ok})
+                         'gather_overlapped': not args.no_overlap, 'gathered_volume_ok': gathered_ok,
+                         'gather_mode': args.gather, 'gather_bytes_per_gate': 45 if args.gather == 'compact' else 76,
+                         'gathered_volume_sha1': volume_sha1, 'per_rank': per_rank})
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -183,20 +183,67 @@ def test_radar_operator_two_ranks_gloo():
     assert _spawn(_worker_operator, ()) is True
 
 
-def test_bench_launches_its_own_ranks():
-    """`bench.py --gpus 2` started plainly (no RANK in the environment) starts two ranks itself; with the CPU
-    stand-in for the kernels the whole multi-rank structure runs here: one volume sharded by azimuth, one gather
-    of all outputs to rank 0 (overlapped with the next volume), one JSON line from rank 0."""
+def _run_bench(extra):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--small', '--stub-engine',
-                        '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=300, env=env)
+                        '--steps', '3', '--warmup', '1'] + extra, capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` started plainly (no RANK in the environment) starts two ranks itself; with the CPU
+    stand-in for the kernels the whole multi-rank structure runs here: one volume sharded by azimuth, one gather
+    of the outputs to rank 0 (overlapped with the next volume), one JSON line from rank 0 that carries the per-rank
+    timings.  The volume that arrives is the same bits whether every field travels every time (--gather full) or the
+    scan geometry travels once and the mask as integer codes (the default)."""
+    d = _run_bench([])
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['steps'] == 3
     assert d['gathered_volume_ok'] is True and d['gather_overlapped'] is True
     assert d['config']['rays_per_rank'] == 72 and 'INVALID' in d['config']['workload']
     assert abs(d['value'] - 144 * d['config']['gates'] * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+    assert d['gather_mode'] == 'compact' and d['gather_bytes_per_gate'] == 45
+    assert [r['rank'] for r in d['per_rank']] == [0, 1]
+    for r in d['per_rank']:
+        assert r['rays'] == 72 and r['compute_ms'] > 0 and r['wait_ms'] >= 0 and r['assemble_ms'] >= 0
+    assert abs(d['compute_ms_per_step_max_rank'] - max(r['compute_ms'] for r in d['per_rank'])) < 1e-9
+    full = _run_bench(['--gather', 'full'])
+    assert full['gather_mode'] == 'full' and full['gather_bytes_per_gate'] == 76 and full['gathered_volume_ok'] is True
+    assert full['gathered_volume_sha1'] == d['gathered_volume_sha1'] and len(d['gathered_volume_sha1']) == 40
+
+
+def test_mask_codes_are_lossless():
+    """The output mask (mean of the sub-beam codes, [0, 1) -> 0, scattering_sz.py:144-151) survives the trip as an
+    integer sum bit for bit, for every possible sum and sub-beam count."""
+    for n_sub in (1, 3, 9, 27, 81, 200):
+        sums = torch.arange(-n_sub, n_sub + 1, dtype=torch.float64)
+        m = sums / n_sub
+        m = torch.where((m >= 0) & (m < 1), torch.zeros_like(m), m)
+        codes = parallel.mask_to_codes(m, n_sub)
+        assert codes.dtype == (torch.int8 if n_sub <= 127 else torch.int16)
+        assert torch.equal(parallel.codes_to_mask(codes, n_sub), m)
+
+
+def test_static_fields_travel_once():
+    """VolumeGather with static fields in a single process: the second start() with the same geometry key packs a
+    shorter row, finish() still returns every field; a new key sends them again."""
+    idx = [np.array([1, 0, 2])]
+    g = parallel.VolumeGather(idx, 3, static=('height',), mask_sub=9)
+    f = OrderedDict(rvel=torch.tensor([[1.], [0.], [2.]]), mask=torch.tensor([[0.], [1.], [-5. / 9.]], dtype=torch.float64),
+                    height=torch.tensor([[10.], [0.], [20.]], dtype=torch.float32))
+    v = g.start(f, geometry_key='a').finish()
+    first = g.layout
+    assert v['height'][:, 0].tolist() == [0., 10., 20.] and v['rvel'][:, 0].tolist() == [0., 1., 2.]
+    assert v['mask'][:, 0].tolist() == [1., 0., -5. / 9.]
+    f2 = OrderedDict(f)
+    f2['rvel'] = f['rvel'] * 2
+    f2['height'] = f['height'] * 0 - 1                      # not sent: same geometry key
+    v = g.start(f2, geometry_key='a').finish()
+    assert [l[0] for l in g.layout] == ['rvel', 'mask'] and len(first) == 3
+    assert v['height'][:, 0].tolist() == [0., 10., 20.] and v['rvel'][:, 0].tolist() == [0., 2., 4.]
+    v = g.start(f2, geometry_key='b').finish()
+    assert v['height'][:, 0].tolist() == [-1., -1., -1.]
