@@ -567,16 +567,40 @@ def main(argv=None):
             flop_per_launch = flop_alg_launch * evaluated
             achieved = flop_per_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
             algorithmic = flop_alg_launch / (ms_int * 1e-3) / 1e12 if ms_int > 0 else 0.
-            traffic = None
+            # HBM bytes per launch and instruction counts are not measured by this run: they come from the hardware-
+            # counter passes of profiles/collect_pmc.py on the same workload (profiles/traffic.json, which names its
+            # source); the launch times beside them are this run's
+            traffic = tsrc = None
+            prof = {}
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tpath) and not args.small and args.config == 'C4' and world == 1:
-                traffic = json.load(open(tpath)).get('k_integrate_hbm_bytes_per_launch')
+            if os.path.exists(tpath) and not args.small and args.config == 'C4' and world == 1 and doppler == 2 and microphysics == 2 and n_gh == 3:
+                prof = json.load(open(tpath))
+                traffic = prof.get('k_integrate_hbm_bytes_per_launch')
+                tsrc = prof.get('source')
             roofline = {'bound': 'mfma', 'kernel': 'k_integrate', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                        'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
                         'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
                         'launches': tim['launches']['integrate'], 'evaluated_fraction': evaluated,
                         'own_quads_fraction': (tim['own_unit_diameters'] / (1024. * tim['valid_units']) if tim['valid_units'] else None),
                         'algorithmic_tflops': algorithmic}
+            # the two other kernels of weight, against the limits that bind them (counts from the same counter passes)
+            others = []
+            ms_front = tim['ms']['interp'] / max(1, tim['launches']['interp'])
+            ms_obs = tim['ms']['observables'] / max(1, tim['launches']['observables'])
+            if prof.get('k_front_valu_insts_per_launch') and ms_front > 0:
+                # a SIMD issues one vector instruction of a wavefront per 4 cycles: 1024 SIMDs x 2.4 GHz / 4
+                peak_v = 1024 * 2.4e9 / 4 / 1e9
+                ach_v = prof['k_front_valu_insts_per_launch'] / (ms_front * 1e-3) / 1e9
+                others.append({'kernel': 'k_front', 'bound': 'valu_issue', 'achieved': ach_v, 'peak': peak_v,
+                               'unit': 'G wavefront-instructions/s', 'frac': ach_v / peak_v, 'avg_launch_ms': ms_front,
+                               'vector_memory_busy_frac': prof.get('k_front_ta_busy_frac'),
+                               'note': 'vector ALU issue and the vector memory path (TA) are both near their limit'})
+            if prof.get('k_gate_reduce_hbm_bytes_per_launch') and ms_obs > 0:
+                ach_b = prof['k_gate_reduce_hbm_bytes_per_launch'] / (ms_obs * 1e-3) / 1e9
+                others.append({'kernel': 'k_gate_reduce (+ k_ray_scan)', 'bound': 'hbm', 'achieved': ach_b, 'peak': 8000.,
+                               'unit': 'GB/s', 'frac': ach_b / 8000., 'avg_launch_ms': ms_obs,
+                               'traffic': prof['k_gate_reduce_hbm_bytes_per_launch']})
+            roofline['other_kernels'] = others
             stage = {k: v / args.steps for k, v in tim['ms'].items()}
             stage['ms_per_step_with_stage_timing'] = dt_instr / args.steps * 1e3
             extra = {'valid_units_per_step': tim['valid_units'] / args.steps,

@@ -51,7 +51,7 @@ class CpolLut(C.Structure):
 class CpolOutputs(C.Structure):
     _fields_ = [('obs', c_float_p), ('rvel', c_double_p), ('mask', c_double_p), ('lat', c_double_p),
                 ('lon', c_double_p), ('dist', c_float_p), ('height', c_float_p), ('ray_status', c_int_p),
-                ('dspectrum', c_double_p)]
+                ('dspectrum', c_double_p), ('diag', c_double_p)]
 
 
 # every symbol include/cosmopol.h declares
@@ -303,8 +303,10 @@ class Context(object):
         self.n_sub = len(a)
 
     # -- hot path ------------------------------------------------------------------
-    def run_rays(self, azimuth, elevation, raise_on_domain=True, check_status=True):
-        """check_status=False leaves every per-ray status (domain, refraction table) to the caller."""
+    def run_rays(self, azimuth, elevation, raise_on_domain=True, check_status=True, diag=False):
+        """check_status=False leaves every per-ray status (domain, refraction table) to the caller.  diag=True adds
+        out['diag'] [n_vars, n_rays, n_gates]: the model variables (upload order, self.var_names) summed over the
+        sub-beams as the reference's diagnostic mode does."""
         az = np.ascontiguousarray(azimuth, dtype=np.float64)
         el = np.ascontiguousarray(elevation, dtype=np.float64)
         R, G = len(az), self.n_gates
@@ -316,9 +318,12 @@ class Context(object):
             out['rvel'] = np.empty((R, G))
         if self.doppler == 3:
             out['dspectrum'] = np.empty((R, G, self.n_vel))
+        if diag:
+            out['diag'] = np.empty((len(self.var_names), R, G))
         o = CpolOutputs(fptr(out['obs']), dptr(out['rvel']) if self.doppler else None, dptr(out['mask']),
                         dptr(out['lat']), dptr(out['lon']), fptr(out['dist']), fptr(out['height']),
-                        iptr(out['ray_status']), dptr(out['dspectrum']) if self.doppler == 3 else None)
+                        iptr(out['ray_status']), dptr(out['dspectrum']) if self.doppler == 3 else None,
+                        dptr(out['diag']) if diag else None)
         rc = self.lib.cpol_run_rays(self.h, R, az.ctypes.data, el.ctypes.data, C.byref(o))
         self._check(rc, 'cpol_run_rays')
         if not check_status:

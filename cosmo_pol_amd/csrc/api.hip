@@ -844,6 +844,9 @@ static int copy_batch_to_host(cpol_ctx *ctx, const cpol_outputs &d, const cpol_o
                                    hipMemcpyDeviceToHost, s));
     if (h.mask) HIPCHK(ctx, hipMemcpyAsync(h.mask + o, d.mask + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (h.ray_status) HIPCHK(ctx, hipMemcpyAsync(h.ray_status + r0, d.ray_status + r0, nr * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (h.diag && d.diag)
+        for (int v = 0; v < ctx->nv; v++)
+            HIPCHK(ctx, hipMemcpyAsync(h.diag + v * RG + o, d.diag + v * RG + o, n * sizeof(double), hipMemcpyDeviceToHost, s));
     return CPOL_OK;
 }
 
@@ -869,8 +872,9 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
         for (int i = 0; i < ctx->nv; i++) have[ctx->var_ids[i]] = true;
         bool ok = have[CPOL_V_T];
         for (int h = 0; h < ct.n_cls; h++) {
-            ok = ok && have[ct.psd[h].q_var] && (ct.psd[h].qn_var < 0 || have[ct.psd[h].qn_var]);
-            if (ctx->cfg.doppler_scheme) ok = ok && have[ct.dop[h].q_var] && (ct.dop[h].qn_var < 0 || have[ct.dop[h].qn_var]);
+            ok = ok && have[ct.psd[h].q_var] && (ct.psd[h].qn_var < 0 || have[ct.psd[h].qn_var]) && have[ct.psd[h].t_var];
+            if (ctx->cfg.doppler_scheme)
+                ok = ok && have[ct.dop[h].q_var] && (ct.dop[h].qn_var < 0 || have[ct.dop[h].qn_var]) && have[ct.dop[h].t_var];
         }
         if (ctx->cfg.doppler_scheme) ok = ok && have[CPOL_V_U] && have[CPOL_V_V] && have[CPOL_V_W] && have[CPOL_V_RHO];
         if (!ok) return fail(ctx, CPOL_ERR_STATE, "the uploaded model lacks a variable the configured schemes read");
@@ -890,6 +894,17 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
         if (ctx->n_vel < 2) return fail(ctx, CPOL_ERR_STATE, "doppler_scheme 3: cpol_set_velocity_bins has not been called");
         if (!out->dspectrum) { TRY(ensure(ctx, w.o_spec, (size_t)RG * ctx->n_vel * sizeof(double))); out->dspectrum = (double *)w.o_spec.p; }
     } else out->dspectrum = nullptr;
+    // diagnostic mode: wanted when the caller (or the host caller behind a ctx-owned device buffer) asks for it
+    const bool want_diag = out->diag || (host && host->diag);
+    if (want_diag && !out->diag) { TRY(ensure(ctx, w.o_diag, (size_t)ctx->nv * RG * sizeof(double))); out->diag = (double *)w.o_diag.p; }
+    DiagVars dv;
+    memset(&dv, 0, sizeof(dv));
+    double diag_sum_w = 0.;
+    if (want_diag) {
+        dv.n = ctx->nv;
+        for (int i = 0; i < ctx->nv; i++) dv.var[i] = ctx->var_ids[i];
+        for (double wq : ctx->weight) diag_sum_w += wq;              // sum_weights += GH_weight, in sub-beam order (interpolation.py:29-31)
+    }
     const double *az_dev = azimuth, *el_dev = elevation;
     if (!no_alloc) {
         // host or device arrays: a copy of either kind puts them on the device
@@ -978,7 +993,7 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
                 fo.E = (float *)w.b_E.p; fo.mask = (signed char *)w.b_mask.p;
                 fo.vals = (float *)w.b_vals.p; fo.plane = nu_max;
                 const int ds = ctx->cfg.doppler_scheme;
-                fo.write_mask = ds == 3 ? ~0u
+                fo.write_mask = (ds == 3 || want_diag) ? ~0u
                               : ds == 2 ? (1u << CPOL_V_RHO | 1u << CPOL_V_U | 1u << CPOL_V_V | 1u << CPOL_V_W)
                               : ds == 1 ? vr1_mask : 0u;
                 fo.dist = out->dist; fo.height = out->height; fo.lat = out->lat; fo.lon = out->lon;
@@ -999,6 +1014,8 @@ static int run_rays_impl(cpol_ctx *ctx, int n_rays, const double *azimuth, const
             TRY(run_physics(ctx, ct, nr, B, G, (const float *)w.b_vals.p, nu_max, (const float *)w.b_E.p,
                             (const signed char *)w.b_mask.p, wsub, (const double *)w.b_phi.p,
                             out->obs, RG, r0, out->mask, out->rvel, out->dspectrum, true));
+            if (want_diag)
+                launch_diag(ctx->stream, nr, B, G, dv, (const float *)w.b_vals.p, nu_max, wsub, diag_sum_w, out->diag, RG, r0);
             if (host) {
                 hipEvent_t done = ctx->copy_events[2 * n_batch + 1];
                 HIPCHK(ctx, hipEventRecord(done, ctx->stream));
@@ -1106,6 +1123,7 @@ extern "C" int cpol_run_rays_async(cpol_ctx *ctx, int n_rays, const double *azim
         TRY(ensure(ctx, b[8], RG * ctx->n_vel * sizeof(double)));
         d.dspectrum = (double *)b[8].p;
     }
+    if (host->diag) { TRY(ensure(ctx, b[9], (size_t)ctx->nv * RG * sizeof(double))); d.diag = (double *)b[9].p; }
     // what the set held before must have left for the host before this call's kernels write into it
     if (ctx->async_done[slot]) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->async_done[slot], 0));
     TRY(run_rays_impl(ctx, n_rays, azimuth, elevation, &d, false, host, true));

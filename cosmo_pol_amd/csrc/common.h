@@ -150,7 +150,7 @@ struct cpol_ctx {
     struct Work {
         Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
             b_sorted, b_urec, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
-            o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, t_a, t_b, t_c, t_d, t_e;
+            o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, o_diag, t_a, t_b, t_c, t_d, t_e;
     };
     Work heap, arena_work;
     Work *w = &heap;
@@ -240,7 +240,7 @@ void launch_spectrum(hipStream_t s, const ClassTable &ct, const SpecParams &sp, 
                      long plane, const float *elev, const signed char *mask, const double *wsub, const double *phi_sc,
                      const double *varray, const float *const *raw, const float *const *d_axis, double *spectrum,
                      double *rvel, long ray0);
-struct Dop2In {                    // inputs of the Doppler scheme-2 reduction inside k_observables
+struct Dop2In {                    // inputs of the Doppler scheme-2 reduction inside k_gate_reduce
     const float  *vals; long plane;
     const float  *elev;
     const double *phi_sc;
@@ -276,6 +276,9 @@ void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu,
                         const double *coef, const float *psd_out, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel);
+struct DiagVars { int n; int var[CPOL_MAX_VARS]; };      // uploaded variables in upload order -> cpol_var slot
+void launch_diag(hipStream_t s, int n_rays, int n_sub, int n_gates, const DiagVars &dv, const float *vals, long plane,
+                 const double *wsub, double sum_w, double *diag, long diag_plane, long ray0);
 void launch_gather_central(hipStream_t s, int n_rays, int n_sub, int n_gates, const float *S, const float *H,
                            const double *lat, const double *lon, float *dist, float *height, double *olat,
                            double *olon, long ray0);

@@ -2256,6 +2256,35 @@ void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu,
                        n_vel);
 }
 
+// Diagnostic mode (interpolation.py:21-51, integrate_GH_pts): every model variable as the weighted sum over the
+// sub-beams, formed like the reference's chain of np.nansum calls: float64, sub-beam after sub-beam, a NaN (the
+// point lies outside the model: all variables of a sub-beam share the first one's mask, :272-278) counting as zero,
+// each term value * weight / sum of the weights in that order.  One thread per (variable, ray, gate).
+__global__ void k_diag(int n_rays, int n_sub, int n_gates, DiagVars dv, const float *__restrict__ vals, long plane,
+                       const double *__restrict__ wsub, double sum_w, double *__restrict__ diag, long diag_plane, long ray0)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)n_rays * n_gates;
+    if (t >= n) return;
+    const int v = blockIdx.y;
+    const int r = (int)(t / n_gates), g = (int)(t % n_gates);
+    const float *src = vals + (long)dv.var[v] * plane;
+    double acc = 0.;
+    for (int b = 0; b < n_sub; b++) {
+        const double y = (double)src[((long)r * n_sub + b) * n_gates + g] * wsub[b] / sum_w;
+        acc += (y != y) ? 0. : y;
+    }
+    diag[(long)v * diag_plane + (ray0 + r) * (long)n_gates + g] = acc;
+}
+
+void launch_diag(hipStream_t s, int n_rays, int n_sub, int n_gates, const DiagVars &dv, const float *vals, long plane,
+                 const double *wsub, double sum_w, double *diag, long diag_plane, long ray0)
+{
+    const long n = (long)n_rays * n_gates;
+    hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256), dv.n), dim3(256), 0, s, n_rays, n_sub, n_gates, dv, vals, plane,
+                       wsub, sum_w, diag, diag_plane, ray0);
+}
+
 // geometry of the central sub-beam (scattering_sz.py:154-157)
 __global__ void k_gather_central(int n_rays, int n_sub, int n_gates, const float *__restrict__ S,
                                  const float *__restrict__ H, const double *__restrict__ lat,

@@ -236,7 +236,7 @@ def any_rank(flag, device=None, group=None):
     return bool(int(t.item()))
 
 
-def run_rays_device(ctx, azimuth, elevation, device):
+def run_rays_device(ctx, azimuth, elevation, device, diag=False):
     """cpol_run_rays_dev into torch tensors on `device` (the rank's GPU): the gather then moves device memory
     over RCCL / xGMI without a detour through the host.  Returns {name: tensor [n_rays, ...]} per ray
     (obs as [n_rays, 9, n_gates]) and the ray status tensor."""
@@ -254,12 +254,15 @@ def run_rays_device(ctx, azimuth, elevation, device):
         t[k] = torch.empty((R, G), dtype=torch.float32, device=device)
     if ctx.doppler == 3:
         t['dspectrum'] = torch.empty((R, G, ctx.n_vel), dtype=torch.float64, device=device)
+    if diag:
+        t['diag'] = torch.empty((len(ctx.var_names), R, G), dtype=torch.float64, device=device)
     status = torch.zeros((R,), dtype=torch.int32, device=device)
     P = lambda x, typ: ctypes.cast(x.data_ptr(), typ)
     o = _lib.CpolOutputs(P(t['obs'], _lib.c_float_p), P(t['rvel'], _lib.c_double_p), P(t['mask'], _lib.c_double_p),
                          P(t['lat'], _lib.c_double_p), P(t['lon'], _lib.c_double_p), P(t['dist'], _lib.c_float_p),
                          P(t['height'], _lib.c_float_p), P(status, _lib.c_int_p),
-                         P(t['dspectrum'], _lib.c_double_p) if ctx.doppler == 3 else None)
+                         P(t['dspectrum'], _lib.c_double_p) if ctx.doppler == 3 else None,
+                         P(t['diag'], _lib.c_double_p) if diag else None)
     torch.cuda.synchronize(device)
     if R:
         ctx.run_rays_dev(az.data_ptr(), el.data_ptr(), R, o)
@@ -267,4 +270,6 @@ def run_rays_device(ctx, azimuth, elevation, device):
     if not ctx.doppler:
         t['rvel'].fill_(float('nan'))
     t['obs'] = t['obs'].permute(1, 0, 2)          # per ray: [n_rays, 9, n_gates]
+    if diag:
+        t['diag'] = t['diag'].permute(1, 0, 2)    # per ray: [n_rays, n_vars, n_gates]
     return t, status

@@ -103,10 +103,8 @@ class RadarOperator(object):
             st.eng.set_refraction(None)
         rank, world = _dist_info()
         n_total = len(azs)
-        if self.diagnostic_mode and world > 1:
-            raise NotImplementedError('diagnostic_mode is served by single-process runs only')
         if world == 1:
-            out = ctx.run_rays(azs, els)      # raises IndexError when a gate leaves the model domain
+            out = ctx.run_rays(azs, els, diag=self.diagnostic_mode)      # raises IndexError when a gate leaves the model domain
             fields = {n: out['obs'][i] for i, n in enumerate(OBS_NAMES)}
             fields['RVEL'] = out['rvel']
             if dscheme in (3, 4):
@@ -114,7 +112,7 @@ class RadarOperator(object):
             extra = {'mask': out['mask'], 'lat': out['lat'], 'lon': out['lon'], 'height': out['height']}
             if self.diagnostic_mode:
                 # radar_operator.py:245-246: the model variables averaged over the sub-beams join the beam's fields
-                fields.update(self._diagnostic_fields(ctx, azs, els, st.quad[2]))
+                fields.update({n: out['diag'][i] for i, n in enumerate(ctx.var_names)})
         else:
             # one process per GPU: every rank simulates its share of the rays (the reference's pool.map over rays,
             # radar_operator.py:253-256) and rank 0 receives the volume in one gather
@@ -126,35 +124,14 @@ class RadarOperator(object):
             if dscheme in (3, 4):
                 fields['DSPECTRUM'] = vol['dspectrum']
             extra = {k: vol[k] for k in ('mask', 'lat', 'lon', 'height')}
+            if self.diagnostic_mode:
+                fields.update({n: vol['diag'][:, i] for i, n in enumerate(ctx.var_names)})
         ranges = st.eng.n_gates and np.arange(cfg.CONFIG['radar']['radial_resolution'] / 2,
                                               cfg.CONFIG['radar']['range'], cfg.CONFIG['radar']['radial_resolution'])
         return SimulatedRadar(scan_type, els, azs, ranges, fields, extra['mask'], extra['lat'], extra['lon'],
                               extra['height'], n_sweeps, rays_per_sweep, self.get_pos_and_time(),
                               fixed_angles=sweep_elev if scan_type == 'ppi' else sweep_az,
                               varray=constants.VARRAY)
-
-    @staticmethod
-    def _diagnostic_fields(ctx, azs, els, weights, rays_per_chunk=64):
-        """interpolation.integrate_GH_pts (interpolation.py:21-51) for every ray: GH-weighted NaN-aware sum of each
-        interpolated model variable over the sub-beams.  Geolocation and interpolation run on the GPU
-        (cpol_geolocate, cpol_interp_points), a chunk of rays at a time; the weighted sum is formed on the host in
-        float64, sub-beam after sub-beam as the reference does."""
-        w = np.asarray(weights, dtype=np.float64)
-        w = w / w.sum()
-        B, G, names = len(w), ctx.n_gates, list(ctx.var_names)
-        out = {n: np.zeros((len(azs), G)) for n in names}
-        for r0 in range(0, len(azs), rays_per_chunk):
-            az, el = azs[r0:r0 + rays_per_chunk], els[r0:r0 + rays_per_chunk]
-            geo = ctx.geolocate(az, el)
-            raw = ctx.interp_points(geo['coords'].reshape(-1, 2), geo['height'].reshape(-1)).reshape(len(names), len(az), B, G)
-            bad = (raw[0] == -9999) | np.isnan(raw[0])          # the first variable's mask serves all (interpolation.py:272-278)
-            for k, n in enumerate(names):
-                v = np.where(bad, np.nan, raw[k]).astype(np.float64)
-                acc = np.zeros((len(az), G))
-                for b in range(B):
-                    acc += np.nan_to_num(v[:, b] * w[b])
-                out[n][r0:r0 + len(az)] = acc
-        return out
 
     def _run_sharded(self, ctx, azs, els, n_sweeps, rays_per_sweep, rank, world):
         """Rays block-cyclic over the ranks, one gather of every output field to rank 0.  With the RCCL backend
@@ -169,13 +146,15 @@ class RadarOperator(object):
         idx = shards[rank]
         if dist.get_backend() == 'nccl':
             dev = torch.device('cuda', self.device)
-            local, status = parallel.run_rays_device(ctx, azs[idx], els[idx], dev)
+            local, status = parallel.run_rays_device(ctx, azs[idx], els[idx], dev, diag=self.diagnostic_mode)
             status = status.cpu().numpy()
         else:
             dev = None
-            out = ctx.run_rays(azs[idx], els[idx], check_status=False)
-            local = OrderedDict((k, torch.as_tensor(out[k])) for k in ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height', 'dspectrum')
+            out = ctx.run_rays(azs[idx], els[idx], check_status=False, diag=self.diagnostic_mode)
+            local = OrderedDict((k, torch.as_tensor(out[k])) for k in ('obs', 'rvel', 'mask', 'lat', 'lon', 'dist', 'height', 'dspectrum', 'diag')
                                 if k in out)
+            if 'diag' in local:
+                local['diag'] = local['diag'].permute(1, 0, 2)
             if 'rvel' not in local:
                 local['rvel'] = torch.full(tuple(local['mask'].shape), float('nan'), dtype=torch.float64)
             local['obs'] = local['obs'].permute(1, 0, 2)

@@ -49,7 +49,7 @@ def get_radar_observables(list_beams, lut_sz, device=0):
 
 def get_pol_from_sz(sz):
     """scattering_sz.py:164-196 for an [n, 12] array of integrated scattering components (host side;
-    the batched path evaluates the same expressions inside k_observables)."""
+    the batched path evaluates the same expressions in float32 inside k_gate_reduce)."""
     wl = constants.WAVELENGTH
     sz = np.asarray(sz)
     b = sz[:, 0] - sz[:, 1] - sz[:, 2] + sz[:, 3]

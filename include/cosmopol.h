@@ -233,6 +233,10 @@ typedef struct {
     float  *dist, *height;
     int    *ray_status;
     double *dspectrum;      /* float64 [n_rays][n_gates][n_vel], doppler_scheme 3 only (doppler_sz.py:91-97) */
+    double *diag;           /* float64 [n_vars][n_rays][n_gates], the reference's diagnostic mode (radar_operator.py:245-246,
+                               interpolation.py:21-51 integrate_GH_pts): every uploaded model variable, in upload order,
+                               as the weighted NaN-aware sum over the sub-beams, sum_b nan0(v_b w_b / sum w).  Unlike
+                               the other members NULL means "not wanted", also for cpol_run_rays_dev */
 } cpol_outputs;
 
 int cpol_run_rays(cpol_ctx *ctx, int n_rays, const double *azimuth, const double *elevation,
@@ -259,7 +263,11 @@ int cpol_wait_async(cpol_ctx *ctx, int calls_back);
  * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same computation and same outputs as
  * cpol_run_rays_dev, bit for bit, but the call allocates nothing: every workspace is a piece of one array of
  * 64 MiB that the library keeps in the device memory of each GPU it runs on until the process ends.  For that:
- *   - n_rays x sub-beams x n_gates must not exceed CPOL_STATIC_MAX_POSITIONS (CPOL_ERR_ARG otherwise);
+ *   - n_rays x sub-beams x n_gates must not exceed CPOL_STATIC_MAX_POSITIONS (CPOL_ERR_ARG otherwise).  That is the
+ *     only size limit: a position takes at most 725 bytes of the array (2-moment input with Doppler scheme 2), 47.5 MB
+ *     at the limit; the sort counters take 520 bytes per lookup-table node and unit kind, and the library accepts at
+ *     most 16384 such nodes (8.5 MB; 7.5 MB for the reference's 46 x 39-node tables of four classes with Doppler
+ *     units of their own), so the two together stay below the 64 MiB whatever the tables;
  *   - azimuth_dev / elevation_dev are DEVICE arrays [n_rays] and are read in place;
  *   - cpol_set_config, cpol_upload_lut, cpol_upload_model and cpol_set_quadrature (which allocate and build the
  *     table images) must have been called before; doppler_scheme 3 is not served (CPOL_ERR_ARG);

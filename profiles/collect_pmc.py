@@ -77,9 +77,19 @@ def main():
         json.dump(result, fh, indent=1, sort_keys=True)
     integ = [v for k, v in result["kernels"].items() if k.startswith("k_integrate<")]
     if integ and "hbm_bytes_per_launch" in integ[0]:
+        t = {"k_integrate_hbm_bytes_per_launch": integ[0]["hbm_bytes_per_launch"],
+             "source": "profiles/%s_pmc.json (rocprofv3 --pmc passes of profiles/collect_pmc.py; 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % tag}
+        fr = result["kernels"].get("k_front", {})
+        if "SQ_INSTS_VALU" in fr:
+            t["k_front_valu_insts_per_launch"] = fr["SQ_INSTS_VALU"]
+        if "TA_TA_BUSY_sum" in fr and "SQ_BUSY_CYCLES" in fr:
+            # TA_TA_BUSY_sum adds the 256 CUs' busy cycles, SQ_BUSY_CYCLES the 32 shader engines'
+            t["k_front_ta_busy_frac"] = (fr["TA_TA_BUSY_sum"] / 256.) / (fr["SQ_BUSY_CYCLES"] / 32.)
+        gr = result["kernels"].get("k_gate_reduce", {})
+        if "hbm_bytes_per_launch" in gr:
+            t["k_gate_reduce_hbm_bytes_per_launch"] = gr["hbm_bytes_per_launch"]
         with open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w") as fh:
-            json.dump({"k_integrate_hbm_bytes_per_launch": integ[0]["hbm_bytes_per_launch"],
-                       "source": "profiles/%s_pmc.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % tag}, fh, indent=1)
+            json.dump(t, fh, indent=1)
     print("done")
 
 

@@ -117,16 +117,20 @@ def test_gather_single_process():
 class _FakeCtx(object):
     """The library context's run_rays with the kernels replaced by a function of (azimuth, elevation, gate)."""
     n_gates, doppler, n_vel, n_sub = 6, 1, 0, 1
+    var_names = ['U', 'T']
 
-    def run_rays(self, az, el, raise_on_domain=True, check_status=True):
+    def run_rays(self, az, el, raise_on_domain=True, check_status=True, diag=False):
         az, el = np.asarray(az, dtype=np.float64), np.asarray(el, dtype=np.float64)
         g = np.arange(self.n_gates)[None, :]
         base = az[:, None] * 10. + el[:, None] * 1000. + g
         status = np.zeros(len(az), dtype=np.int32)
         status[(el > 80.)] = 4          # "leaves the model domain"
-        return {'obs': np.stack([(base + 0.5 * i).astype(np.float32) for i in range(9)]), 'rvel': base * 2., 'mask': base * 0.,
-                'lat': base + 0.25, 'lon': base + 0.75, 'dist': g.astype(np.float32) + 0 * base.astype(np.float32),
-                'height': (base * 3).astype(np.float32), 'ray_status': status}
+        out = {'obs': np.stack([(base + 0.5 * i).astype(np.float32) for i in range(9)]), 'rvel': base * 2., 'mask': base * 0.,
+               'lat': base + 0.25, 'lon': base + 0.75, 'dist': g.astype(np.float32) + 0 * base.astype(np.float32),
+               'height': (base * 3).astype(np.float32), 'ray_status': status}
+        if diag:
+            out['diag'] = np.stack([base * 7. + 1., base * 11. + 2.])          # [variables, rays, gates]
+        return out
 
 
 def _worker_operator(rank, world, port, q):
@@ -163,6 +167,18 @@ def _worker_operator(rank, world, port, q):
                 ok = ok and np.array_equal(radar.gate_altitude['data'], want['height'])
             else:
                 assert radar is None
+        # diagnostic mode: the sub-beam sums of the model variables travel with the volume (radar_operator.py:245-246)
+        opd = RadarOperator(conf, diagnostic_mode=True)
+        opd.dic_vars, opd.lut_sz = op.dic_vars, {}
+        els, azs = [3.], np.arange(0., 50., 10.)
+        radar = opd.get_PPI(els, azimuths=azs)
+        if rank == 0:
+            want = _FakeCtx().run_rays(azs, np.repeat(els, len(azs)), diag=True)
+            ok = ok and np.array_equal(radar.fields['U']['data'].filled(np.nan), want['diag'][0])
+            ok = ok and np.array_equal(radar.fields['T']['data'].filled(np.nan), want['diag'][1])
+            ok = ok and np.array_equal(radar.fields['ZH']['data'].filled(np.nan), 10 * np.log10(want['obs'][0]))
+        else:
+            assert radar is None
         # a ray that leaves the domain on ONE rank raises on both (no rank is left waiting in the gather)
         try:
             op.get_RHI(30., elevations=[10., 85.])

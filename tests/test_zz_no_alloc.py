@@ -94,3 +94,30 @@ def test_run_rays_static_refuses_what_it_cannot_hold():
     eng3.set_gauss_hermite()
     with pytest.raises(_lib.CosmoPolError, match='doppler_scheme 3'):
         eng3.ctx.run_rays_static(az.data_ptr(), el.data_ptr(), 2)
+
+
+def test_run_rays_static_at_its_limit_with_reference_sized_tables():
+    """The static array also holds the sort counters, which grow with the number of lookup-table nodes, not with the
+    positions: the largest call (CPOL_STATIC_MAX_POSITIONS positions, 2-moment input, Doppler units of their own)
+    with tables of the reference's size (46 elevations x 39 temperatures, compute_lut_sz.py:30-32) still fits, and
+    gives what cpol_run_rays_dev gives."""
+    import torch
+    dev = torch.device('cuda', 0)
+    conf = pipeline_conf(2, 3, 3, dscheme=2)
+    m = pipeline_model(2)
+    eng = make_engine(conf, n_e=46, n_t=None)
+    eng.upload_model(m['fields'], m['zlev'], m['proj_info'], m['resolution'])
+    eng.set_gauss_hermite()
+    ctx, G = eng.ctx, eng.n_gates
+    n_rays = _lib.STATIC_MAX_POSITIONS // (ctx.n_sub * G)
+    rng = np.random.default_rng(3)
+    az = torch.tensor(rng.uniform(0., 360., n_rays), dtype=torch.float64, device=dev)
+    el = torch.tensor(rng.uniform(0.5, 40., n_rays), dtype=torch.float64, device=dev)
+    want_t, want_o = _device_outputs(torch, n_rays, G, dev)
+    ctx.run_rays_dev(az.data_ptr(), el.data_ptr(), n_rays, want_o)
+    ctx.synchronize()
+    got_t, got_o = _device_outputs(torch, n_rays, G, dev)
+    ctx.run_rays_static(az.data_ptr(), el.data_ptr(), n_rays, got_o)
+    ctx.synchronize()
+    for k in want_t:
+        assert got_t[k].cpu().numpy().tobytes() == want_t[k].cpu().numpy().tobytes(), k
