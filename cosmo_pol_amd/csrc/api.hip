@@ -540,17 +540,27 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
             HIPCHK(ctx, hipGetLastError());
             // term cutoff of the class: the smallest exponent its tables are certified for, else exact zeros only
             L.cut_e = 152.f;
+            L.cut_e_dop = 152.f;
             {
                 bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
                 for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
+                const double cand[] = {48., 56., 64., 72., 80., 96., 112., 128.};
+                if (ctx->certified_cutoff && asc && !ctx->cert_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->cert_dev, sizeof(float)));
                 if (ctx->certified_cutoff && asc && L.psd.nu > 0.) {
-                    if (!ctx->cert_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->cert_dev, sizeof(float)));
-                    const double cand[] = {48., 56., 64., 72., 80., 96., 112., 128.};
                     for (double e : cand) {
                         const float worst = cut_certificate(ctx->stream, L.raw, L.d_axis, nslice, L.psd.mu, L.psd.nu,
                                                             xref_of(L, L.psd.nu), shared ? 1 : 0, L.psd_dop.mu, L.psd_dop.alpha,
                                                             L.psd_dop.beta, e, ctx->cert_dev);
                         if (worst <= 3.7252903e-09f) { L.cut_e = (float)(e + 2.); break; }      // 2^-28
+                    }
+                }
+                // the separate Doppler units integrate the two moments under their own PSD: a certificate of their own
+                if (ctx->certified_cutoff && asc && want_dop_img && L.psd_dop.nu > 0.) {
+                    for (double e : cand) {
+                        const float worst = cut_certificate(ctx->stream, L.raw, L.d_axis, nslice, L.psd_dop.mu, L.psd_dop.nu,
+                                                            (double)(float)xref_of(L, L.psd_dop.nu), 2, L.psd_dop.mu, L.psd_dop.alpha,
+                                                            L.psd_dop.beta, e, ctx->cert_dev);
+                        if (worst <= 3.7252903e-09f) { L.cut_e_dop = (float)(e + 2.); break; }
                     }
                 }
             }
@@ -571,6 +581,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
         ct.cut_ok[h] = (asc && L.psd.nu > 0.) ? 1 : 0;
         ct.cut_e[h] = L.cut_e;
         ct.dop_cut_ok[h] = (asc && L.psd_dop.nu > 0.) ? 1 : 0;
+        ct.dop_cut_e[h] = L.cut_e_dop;
         ct.pol_geo_step[h] = (L.axis_uniform && L.psd.nu == 1.0) ? (float)(4. * L.axis_step) : 0.f;
         ct.dop_geo_step[h] = (L.axis_uniform && L.psd_dop.nu == 1.0) ? (float)L.axis_step : 0.f;
         fill_psd(ct.psd[h], L.psd);

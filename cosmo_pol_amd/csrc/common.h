@@ -36,6 +36,7 @@ struct LutDev {
     std::vector<float> d_host;     // the diameter axis as uploaded
     int    image_ncol = 0;         // what `table` was last built for
     float  cut_e = 152.f;          // term cutoff exponent the tables of this class are certified for (see k_cut_certificate)
+    float  cut_e_dop = 152.f;      // the same for the separate Doppler units (their own PSD)
     cpol_psd psd, psd_dop;
 };
 
@@ -79,6 +80,7 @@ struct ClassTable {
     int     cut_ok[CPOL_MAX_CLASSES];          // D^nu ascending along the diameter axis
     float   cut_e[CPOL_MAX_CLASSES];           // terms with N(D) < 2^-(cut_e - 2) N(D_0) are left out (152: exact float32 zeros only)
     int     dop_cut_ok[CPOL_MAX_CLASSES];      // same for the Doppler PSD's nu
+    float   dop_cut_e[CPOL_MAX_CLASSES];       // cutoff exponent of the separate Doppler units
 };
 
 struct ModelView {

@@ -820,6 +820,8 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
 // maximum over everything goes to *worst; the host accepts cut_e when it is below 2^-28, a sixteenth of float32's
 // resolution.  A combination that changes sign along the diameter axis can have a unit value near zero at some
 // slope; the ratio is then large and the class keeps the exact-zero rule, which is always safe.
+// with_dop: 0 = the polarimetric quantities, 1 = those and the two Doppler moments under the same PSD, 2 = the two
+// Doppler moments alone under the PSD passed as (mu, nu, x_ref) = (mu_d, ...): the separate Doppler units.
 #define CERT_SAMPLES 4
 #define CERT_NG 9
 __global__ __launch_bounds__(256)
@@ -859,6 +861,10 @@ void k_cut_certificate(const float *__restrict__ raw, const float *__restrict__ 
         if (with_dop) {
             const double rcs = 2 * M_PI * ((((double)src[0] - src[1]) - src[2]) + src[3]) * pow(D, mu_d) * n;
             g[7] = rcs; g[8] = rcs * alpha_d * pow(D, beta_d);
+        }
+        if (with_dop == 2) {                               // the Doppler units' own PSD (mu, nu are its): the two moments only
+#pragma unroll
+            for (int j = 0; j < 7; j++) g[j] = 0.;
         }
 #pragma unroll
         for (int j = 0; j < NG; j++) { tot[j] += g[j]; if (d >= c) tail[j] += fabs(g[j]); }
@@ -1795,9 +1801,9 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
 // =============================================================================
 #define DOP_THREADS (CPOL_CHUNK_UNITS / 2)      // two units per lane: every LDS word read serves both
 
-// plain path of one unit: one exponential per diameter, over the first nq8 quads (a multiple of 8); the two
-// moments of a diameter are accumulated as one packed pair
-__device__ inline void dop_unit_plain(const float *lds, float2 l, int nq8, double *o12, double *o13)
+// plain path of one unit: one exponential per diameter, over the first nq8 quads (a multiple of 8) and no further
+// than the unit's own quad count; the two moments of a diameter are accumulated as one packed pair
+__device__ inline void dop_unit_plain(const float *lds, float2 l, int nq8, int own, double *o12, double *o13)
 {
     const f32x2 *BB = (const f32x2 *)(lds + 1024);
     double s12 = 0., s13 = 0.;
@@ -1806,7 +1812,8 @@ __device__ inline void dop_unit_plain(const float *lds, float2 l, int nq8, doubl
 #pragma unroll 8
         for (int d = d0; d < d0 + 128; d++) {
             const float x = lds[d];
-            const float n = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x, -l.y * x));
+            float n = __builtin_amdgcn_exp2f(__builtin_fmaf(-l.x, x, -l.y * x));
+            n = d < 16 * own ? n : 0.f;          // the unit's own quads only
             a = __builtin_elementwise_fma((f32x2){n, n}, BB[d], a);
         }
         s12 += (double)a.x;
@@ -1884,7 +1891,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
             if (n0_[t] == 0.) nqu[t] = 0;
             else if (cut_ok) {
                 const float2 lt = lt_[t];
-                const float xc = psd_cutoff_x(lt.x + lt.y);
+                const float xc = psd_cutoff_x(lt.x + lt.y, ct.dop_cut_e[h]);
                 int c = 0;
 #pragma unroll
                 for (int step = 64; step >= 1; step >>= 1)
@@ -1920,14 +1927,18 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     if (work && lane == 0)
         atomicAdd(&work[(CPOL_WORK_SLOTS + ((blockIdx.x * (DOP_THREADS / 64) + (tid >> 6)) & (CPOL_WORK_SLOTS - 1))) * CPOL_WORK_STRIDE],
                   (unsigned long long)nq8 * (unsigned)min(cnt - wbase, 128));
-    int slot[2];
+    int slot[2], own[2];
     float2 l[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const float4 ur = have[t] ? s_u[pos[t]] : make_float4(0.f, 0.f, 0.f, 0.f);
         slot[t] = __float_as_int(ur.z);
+        own[t] = __float_as_int(ur.w);          // quads the unit itself takes part in
         l[t] = make_float2(ur.x, ur.y);
     }
+    // below the exact-zero rule the terms past a unit's own count are small, not zero: they are left out per unit,
+    // so that a unit's sums do not depend on which units share its wavefront
+    const int own_lo = __builtin_amdgcn_readfirstlane(__float_as_int(s_u[wbase].w));
     if (nq8 == 0) {          // nothing to integrate for any unit of the wavefront
 #pragma unroll
         for (int t = 0; t < 2; t++)
@@ -1981,7 +1992,9 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
                     }
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
-                        acc[t] = __builtin_elementwise_fma((f32x2){nq_[t], nq_[t]}, S[t], acc[t]);
+                        float nn = nq_[t];
+                        if (qo + q4 + m >= own_lo) nn = qo + q4 + m < own[t] ? nn : 0.f;      // wave-uniform test first
+                        acc[t] = __builtin_elementwise_fma((f32x2){nn, nn}, S[t], acc[t]);
                         nq_[t] *= R16[t];
                     }
                 }
@@ -1991,7 +2004,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
         }
     } else {
         for (int t = 0; t < 2; t++)
-            if (have[t]) dop_unit_plain(lds, l[t], nq8, &s12[t], &s13[t]);
+            if (have[t]) dop_unit_plain(lds, l[t], min(nq8, (own[t] + 7) & ~7), own[t], &s12[t], &s13[t]);
     }
     // unit-spacing trapezoid rule (doppler_sz.py:219-220): the sum minus half of the two end terms
     const float x0 = lds[0], xl = lds[1023];
@@ -2148,46 +2161,23 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     if (rvel_out && (op.doppler == 1 || op.doppler == 2)) rvel_out[o] = rv / sw;
 }
 
-// Inclusive float32 running sum / product over the 64 lanes of a wavefront in the reference's order:
-// acc_i = fl(acc_{i-1} (op) x_i), one rounding per gate, exactly what np.cumsum / np.cumprod do on a float32
-// array (utilities.py:18-24).  Every lane walks the wave's 64 values (v_readlane, no LDS) and stops taking
-// part after its own; `carry` is the value before lane 0 and returns as the value after lane 63.
-__device__ inline float wave_seq_sum(float x, int lane, float &carry)
-{
-    float acc = carry;
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
-        const float t = acc + v;
-        acc = i <= lane ? t : acc;
-    }
-    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
-    return acc;
-}
-
-__device__ inline float wave_seq_prod(float x, int lane, float &carry)
-{
-    float acc = carry;
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), i));
-        const float t = acc * v;
-        acc = i <= lane ? t : acc;
-    }
-    carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
-    return acc;
-}
-
 // Stage 2, one wavefront per ray: PHIDP and the attenuation as sequential float32 scans along range (the
-// reference's accumulation order and precision), sensitivity cut.
+// reference's accumulation order and precision: acc_i = fl(acc_{i-1} (op) x_i), one rounding per gate, exactly what
+// np.cumsum / np.cumprod do on a float32 array, utilities.py:18-24), then the sensitivity cut.
+// The three scans (sum of 2 KDP, products of the two attenuation factors) of a chunk of 64 gates run side by side
+// on lanes 0..2, each as a chain of 64 fused multiply-adds acc = fma(acc, m, a) over operands the 64 lanes put into
+// LDS: (m, a) = (1, x) makes the step the correctly rounded sum acc + x, (x, 0) the correctly rounded product acc x
+// (factors and products are positive, so no signed zero is at stake).
 __global__ __launch_bounds__(64)
 void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0,
                 double *__restrict__ rvel_out, double *__restrict__ spectrum, int n_vel)
 {
+    __shared__ float2 s_op[3][64];
+    __shared__ float s_pre[3][64];
     const int r = blockIdx.x, lane = threadIdx.x;
     const int G = op.n_gates;
     const float qnan = __builtin_nanf("");
-    float carry_phi = 0.f, carry_h = 1.f, carry_v = 1.f;
+    float carry = lane == 0 ? 0.f : 1.f;          // lane 0: running sum; lanes 1, 2: running products
     for (int g0 = 0; g0 < G; g0 += 64) {
         const int g = g0 + lane;
         const bool act = g < G;
@@ -2197,21 +2187,35 @@ void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0
         const float ah = obs[CPOL_O_AH * obs_plane + o], av = obs[CPOL_O_AV * obs_plane + o];
         // PHIDP = nan_cumsum(2 * KDP_m) * res / 1000  (scattering_sz.py:118)
         const float two_k = 2.f * kdpm;
-        const float sc = wave_seq_sum((act && two_k == two_k) ? two_k : 0.f, lane, carry_phi);
-        const float phidp = sc * op.res / 1000.f;
-        bool att = false;
-        float zdr = 0.f;
+        s_op[0][lane] = make_float2(1.f, (act && two_k == two_k) ? two_k : 0.f);
         if (op.att_corr) {
             // ZV *= nan_cumprod(10 ** (-0.1 * AV * res_km)), the same for ZH  (scattering_sz.py:120-123)
             // the factor is the correctly rounded float32 power (float64 evaluation, one rounding), what a libm
-            // powf returns; NumPy's vectorised float32 power differs from it in the last bit for 10-20 % of
+            // powf returns; NumPy's vectorised float32 power differs from it in the last bit for some 12 % of
             // arguments, depending on the CPU it runs on
             const float fh = (float)exp10((double)((-0.1f * ah) * op.res_km));
             const float fv = (float)exp10((double)((-0.1f * av) * op.res_km));
-            const float ph = wave_seq_prod((act && fh == fh) ? fh : 1.f, lane, carry_h);
-            const float pv = wave_seq_prod((act && fv == fv) ? fv : 1.f, lane, carry_v);
-            zv *= pv;
-            zh *= ph;
+            s_op[1][lane] = make_float2((act && fh == fh) ? fh : 1.f, 0.f);
+            s_op[2][lane] = make_float2((act && fv == fv) ? fv : 1.f, 0.f);
+        }
+        __syncthreads();
+        if (lane == 0 || (op.att_corr && lane < 3)) {
+            float acc = carry;
+#pragma unroll 16
+            for (int i = 0; i < 64; i++) {
+                const float2 ma = s_op[lane][i];
+                acc = fmaf(acc, ma.x, ma.y);
+                s_pre[lane][i] = acc;
+            }
+            carry = acc;
+        }
+        __syncthreads();
+        const float phidp = s_pre[0][lane] * op.res / 1000.f;
+        bool att = false;
+        float zdr = 0.f;
+        if (op.att_corr) {
+            zv *= s_pre[2][lane];
+            zh *= s_pre[1][lane];
             zdr = zh / zv;
             att = true;
         }
