@@ -1579,129 +1579,114 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     }
     __syncthreads();
 
-    const int kq = lane >> 4, j = lane & 15;
+    // ---- the passes: v_mfma_f32_4x4x1_16b_f32 ----
+    // One instruction holds sixteen independent 4 x 4 x 1 products: block b = lane >> 2 takes A[b][i] from lane
+    // 4 b + i, B[b][j] from lane 4 b + j and adds the outer product to D[b][i][j] = register i of lane 4 b + j.
+    // Here a block is (ug, dr): a subgroup of four units (ug = lane >> 4, unit i = lane & 3 inside it) and a
+    // diameter residue dr = (lane >> 2) & 3, so one instruction multiplies 16 units' N(D) values at four
+    // diameters d = 16 q + 4 s + dr (step s of quad q) into four columns of the table, and NG = NC / 4
+    // instructions (8 cycles each) take a set of 16 units through all columns: 24 matrix cycles per 64
+    // (unit, diameter) terms with the twelve scattering components where the 16 x 16 x 4 shape, a quarter of
+    // whose columns would be padding, needs 32.  The lane's B word of quad q and column group g is word
+    // (4 q + dr) NC + 4 g + (lane & 3) of the image: its operands of the four steps in one 16-byte read, the
+    // same word in the four subgroups (a broadcast), the 16 distinct words of a read in 16 different bank
+    // quarters when NC = 12.  Every lane generates one N(D) value per step and set of 16 units, for the unit
+    // (ug, lane & 3), so nothing is computed twice.  The four residues' partial sums (at most 256 float32
+    // additions each over the whole axis) meet at the end of the pass.
+    constexpr int NG = (NC + 3) / 4;
+    const int ug = lane >> 4, dr = (lane >> 2) & 3, r4 = lane & 3;
     const float4 *B4 = (const float4 *)lds;
-    const float4 *X4 = (const float4 *)(lds + LDS_X) + kq;
-    // float4 index of this lane's operand word: quad q -> bbase + q * bstride.  Which of the 16 lanes of a row
-    // (k = kq) carries which column matters for the LDS: a ds_read_b128 is served in four groups of 16 lanes -
-    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same 32 lanes up - each conflict-free when its 16 words fall
-    // into 16 different quarters of the 64 banks.  A group is half of one row and the other half of the next, 12
-    // words further on, so with NC = 12 the columns are dealt to the lanes such that the two halves of a row hold
-    // complementary residues: lanes {0-3, 12, 13} take columns 0 4 8 1 5 9, lanes {4-9} columns 2 6 10 3 7 11, and the
-    // spare lanes {14, 15} and {10, 11} read a zero word in a quarter their group leaves free.
-    int comp = j, bbase, bstride;
-    if constexpr (NC == 12) {
-        const int half = (j >= 4 && j < 12) ? 1 : 0;
-        const int jj = half ? j - 4 : (j < 4 ? j : j - 8);           // 0..7 inside the half, 6 and 7 spare
-        const bool real = jj < 6;
-        comp = real ? (jj % 3) * 4 + jj / 3 + 2 * half : 12 + 2 * half + (jj - 6);
-        const int grp = 2 * (kq >> 1) + ((kq & 1) ^ half);
-        const int zero_quarter = grp == 0 ? 12 : grp == 1 ? 8 : grp == 2 ? 2 : 0;
-        bbase = real ? kq * NC + comp : LDS_ZERO / 4 + zero_quarter;
-        bstride = real ? 4 * NC : 0;
-    } else {
-        // (the zero word of a 16-lane group sits in the banks its NC real words leave free)
-        bbase = j < NC ? kq * NC + j : (LDS_ZERO + ((kq * NC * 4 + NC * 4) & 63)) / 4;
-        bstride = j < NC ? 4 * NC : 0;
-    }
+    const float4 *X4 = (const float4 *)(lds + LDS_X) + dr;
+    int boff[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) boff[g] = dr * NC + 4 * g + r4;
+    // columns past NC (NC = 14: the last two of the fourth group): a zero word, the same for every quad
+    const bool spare = 4 * (NG - 1) + r4 >= NC;
+    const int bstride_last = spare ? 0 : 4 * NC;
+    if (spare) boff[NG - 1] = LDS_ZERO / 4 + dr;
     const int npass = (cnt + 31) >> 5;
     unsigned wsum = 0, own = 0;
+    auto mfma4 = [](float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); };
 
-    // passes of 32 units in cutoff order; the waves take them in snake order (0 1 2 ... 7 7 6 ... 0 ...) so
-    // that every wave gets cheap and expensive ones
+    // passes of 32 units in cutoff order, two sets of 16; the waves take them in snake order (0 1 2 ... 7 7 6 ... 0
+    // ...) so that every wave gets cheap and expensive ones
     constexpr int NW = INTEG_THREADS / 64;
-    for (int r4 = 0; r4 * NW < npass; r4++) {
-        const int ps = r4 * NW + ((r4 & 1) ? NW - 1 - wave : wave);
+    for (int r8 = 0; r8 * NW < npass; r8++) {
+        const int ps = r8 * NW + ((r8 & 1) ? NW - 1 - wave : wave);
         if (ps >= npass) continue;
-        const int g0 = ps * 2;
-        // two groups of 16 units per pass: two independent accumulators, and the two units'
-        // exponent arguments are formed side by side
-        int ua = g0 * 16 + j, ub = ua + 16;
+        const int u0 = ps * 32;
+        const int ua = u0 + ug * 4 + r4, ub = ua + 16;        // the lane's unit in either set
         // per unit lambda*log2(e) = hi + lo (two floats): exp(-lambda x) = exp2(-(hi x + lo x))
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
         if (ua < cnt) ra = urec[start + ua];
         if (ub < cnt) rb = urec[start + ub];
-        const float2 la = make_float2(ra.x, ra.y), lb = make_float2(rb.x, rb.y);
-        const int nqa = __float_as_int(ra.z), nqb = __float_as_int(rb.z);      // quads each of the lane's two units takes part in
-        const f32x2 nhi = {-la.x, -lb.x}, nlo = {-la.y, -lb.y};
-        double da[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
-        // The pass runs up to the quad count of its last unit in cutoff order (lane 15's second unit, or the
-        // chunk's last); up to the count of its first unit every unit takes part, beyond it a unit's N(D) is
-        // set to zero once its own count is reached, so that a unit's sums cover its own quads whatever units
-        // share its pass.
-        const int ulast = min(g0 * 16 + 31, cnt - 1);
-        const int nq = __shfl(ulast >= g0 * 16 + 16 ? nqb : nqa, ulast & 15);
-        const int nq_lo = __shfl(nqa, 0);
-        wsum += (unsigned)nq * (unsigned)min(cnt - g0 * 16, 32);
-        if (kq == 0) own += (unsigned)((ua < cnt ? nqa : 0) + (ub < cnt ? nqb : 0));      // the units' own quad counts
+        const int nqa = __float_as_int(ra.z), nqb = __float_as_int(rb.z);      // quads the lane's units take part in
+        const float nha = -ra.x, nla = -ra.y, nhb = -rb.x, nlb = -rb.y;
+        // Units come in cutoff order, so the first set ends no later than the second begins: both sets run up to
+        // the quad count of the first set's last unit, the second alone from there to that of its own last unit.
+        // Past the count of a set's first unit a lane sets its N(D) to zero once its own unit's count is reached:
+        // a unit's sums cover its own quads whatever units share its pass.
+        const int n_a = min(cnt - u0, 16), n_b = max(0, min(cnt - u0 - 16, 16));
+        const int a_lo = __shfl(nqa, 0), a_hi = __shfl(nqa, ((n_a - 1) >> 2) * 16 + ((n_a - 1) & 3));
+        const int b_lo = n_b ? __shfl(nqb, 0) : 0;
+        const int b_hi = n_b ? __shfl(nqb, ((n_b - 1) >> 2) * 16 + ((n_b - 1) & 3)) : 0;
+        if (dr == 0) own += (unsigned)((ua < cnt ? nqa : 0) + (ub < cnt ? nqb : 0));      // the units' own quad counts
+        f32x4 acca[NG], accb[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) { acca[g] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[g] = acca[g]; }
         if (gstep > 0.f) {
             // nu = 1 on a uniform diameter axis: N(D) is a geometric sequence.  A lane's four values of a quad
             // are 4 diameters apart (ratio R per unit), the same lane's values of the next quad 16 further
-            // (ratio R^4): one exponential per unit seeds four quads, the rest are packed multiplications (at
-            // most five roundings from the seed).  Seed groups are evaluated whole: one that is skipped starts
-            // beyond every cutoff, so its seed is an exact zero.
-            const f32x2 arg = {la.x * gstep + la.y * gstep, lb.x * gstep + lb.y * gstep};
-            const f32x2 Rv = {__builtin_amdgcn_exp2f(-arg.x), __builtin_amdgcn_exp2f(-arg.y)};
-            const f32x2 R2v = Rv * Rv;
-            const f32x2 R4v = R2v * R2v;
-            // one seed group: quads q0 .. q0+3
-            const int nqa4 = (nqa + 3) & ~3, nqb4 = (nqb + 3) & ~3, lo4 = (nq_lo + 3) & ~3;
-            auto seed_group = [&](int q0, f32x4 &acca, f32x4 &accb) {
+            // (ratio R^4): one exponential per unit seeds four quads, the rest are multiplications (at most five
+            // roundings from the seed).  Seed groups are evaluated whole: one that is skipped starts beyond every
+            // cutoff, so its seed is an exact zero.
+            const float Ra = __builtin_amdgcn_exp2f(-(ra.x * gstep + ra.y * gstep)), Rb = __builtin_amdgcn_exp2f(-(rb.x * gstep + rb.y * gstep));
+            const float R2a = Ra * Ra, R2b = Rb * Rb, R4a = R2a * R2a, R4b = R2b * R2b;
+            const int nqa4 = (nqa + 3) & ~3, nqb4 = (nqb + 3) & ~3;
+            const int a_hi4 = (a_hi + 3) & ~3, b_hi4 = (b_hi + 3) & ~3;
+            wsum += (unsigned)a_hi4 * (unsigned)n_a + (unsigned)b_hi4 * (unsigned)n_b;
+            // one seed group of one set: quads q0 .. q0 + 3
+            auto seed_group = [&](int q0, float nh, float nl, float R, float R2, float R4, bool live, f32x4 *acc) {
                 const float x0 = X4[q0 * 4].x;
-                const f32x2 x2 = {x0, x0};
-                const f32x2 p = __builtin_elementwise_fma(nhi, x2, nlo * x2);
-                f32x2 n0 = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
-                if (q0 >= lo4) {          // a unit that has had its seed groups: zero seed, zero terms
-                    n0.x = q0 < nqa4 ? n0.x : 0.f;
-                    n0.y = q0 < nqb4 ? n0.y : 0.f;
-                }
-                f32x2 n1 = n0 * Rv, n2 = n0 * R2v;
-                f32x2 n3 = n1 * R2v;
+                float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(nh, x0, nl * x0));
+                n0 = live ? n0 : 0.f;          // a unit that has had its seed groups: zero seed, zero terms
+                float n1 = n0 * R, n2 = n0 * R2;
+                float n3 = n1 * R2;
 #pragma unroll
                 for (int m = 0; m < 4; m++) {
-                    const float4 bq = B4[bbase + (q0 + m) * bstride];
+                    float4 bq[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; g++) bq[g] = B4[boff[g] + (q0 + m) * (g == NG - 1 ? bstride_last : 4 * NC)];
                     __builtin_amdgcn_sched_barrier(0);
-                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n0.x, bq.x, acca, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n0.y, bq.x, accb, 0, 0, 0);
-                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n1.x, bq.y, acca, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n1.y, bq.y, accb, 0, 0, 0);
-                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n2.x, bq.z, acca, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n2.y, bq.z, accb, 0, 0, 0);
-                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(n3.x, bq.w, acca, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(n3.y, bq.w, accb, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) acc[g] = mfma4(n0, bq[g].x, acc[g]);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) acc[g] = mfma4(n1, bq[g].y, acc[g]);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) acc[g] = mfma4(n2, bq[g].z, acc[g]);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) acc[g] = mfma4(n3, bq[g].w, acc[g]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (m < 3) { n0 = n0 * R4v; n1 = n1 * R4v; n2 = n2 * R4v; n3 = n3 * R4v; }
+                    if (m < 3) { n0 = n0 * R4; n1 = n1 * R4; n2 = n2 * R4; n3 = n3 * R4; }
                 }
             };
-            const int nq4 = (nq + 3) & ~3;
-            // float64 flush every 128 diameters (two seed groups), whatever the pass's length
-            for (int qo = 0; qo + 8 <= nq4; qo += 8) {
-                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-                seed_group(qo, acca, accb);
-                seed_group(qo + 4, acca, accb);
-#pragma unroll
-                for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
+            for (int q0 = 0; q0 < a_hi4; q0 += 4) {
+                seed_group(q0, nha, nla, Ra, R2a, R4a, q0 < nqa4, acca);
+                if (n_b) seed_group(q0, nhb, nlb, Rb, R2b, R4b, true, accb);
             }
-            if (nq4 & 4) {
-                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-                seed_group(nq4 - 4, acca, accb);
-#pragma unroll
-                for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
-            }
+            for (int q0 = a_hi4; q0 < b_hi4; q0 += 4) seed_group(q0, nhb, nlb, Rb, R2b, R4b, q0 < nqb4, accb);
         } else {
-            auto quad = [&](int qd, f32x4 &acca, f32x4 &accb) {
-                float4 bq = B4[bbase + qd * bstride];
-                const bool tail = qd >= nq_lo;         // wave-uniform: some units of the pass are past their own count
-                float4 xq = X4[qd * 4];
-                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+            wsum += (unsigned)a_hi * (unsigned)n_a + (unsigned)b_hi * (unsigned)n_b;
+            // Exponent argument -(hi + lo) x: the hi part by one fused multiply-add per value, the lo part (2^-24 of
+            // it) with the quad's third abscissa instead of x itself - the difference, lo (x - x_mid), is below
+            // the rounding of the argument at the quad's far end.  All N(D) values of the quad first (independent
+            // registers), then the matrix instructions back to back: none waits for a transcendental result.
+            auto quad2 = [&](int qd) {          // both sets
+                float4 bq[NG];
+#pragma unroll
+                for (int g = 0; g < NG; g++) bq[g] = B4[boff[g] + qd * (g == NG - 1 ? bstride_last : 4 * NC)];
+                const float4 xq = X4[qd * 4];
                 const float xx[4] = {xq.x, xq.y, xq.z, xq.w};
-                // all eight N(D) values of the quad first (independent registers), then the
-                // eight MFMAs back to back: no MFMA waits for a transcendental result.
-                // Exponent argument -(hi + lo) x: the hi part by one fused multiply-add per value, the lo part (2^-24 of
-                // it) with the quad's middle abscissa instead of x itself - the difference, lo (x - x_mid), is below
-                // the rounding of the argument at the quad's far end.  Plain float32 instructions in one block: beside
-                // the matrix instructions a packed v_pk_mul_f32 + v_pk_fma_f32 pair for both units costs more issue
-                // time than the separate instructions (measured), and the compiler would pack them again.
                 float na[4], nb_[4];
                 {
                     float ta, tb, p0, p1, p2, p3, p4, p5, p6, p7;
@@ -1717,54 +1702,93 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                                  "v_fma_f32 %9, %11, %17, %1"
                                  : "=&v"(ta), "=&v"(tb), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5),
                                    "=&v"(p6), "=&v"(p7)
-                                 : "v"(nhi.x), "v"(nhi.y), "v"(nlo.x), "v"(nlo.y), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
+                                 : "v"(nha), "v"(nhb), "v"(nla), "v"(nlb), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
                     na[0] = __builtin_amdgcn_exp2f(p0); nb_[0] = __builtin_amdgcn_exp2f(p1);
                     na[1] = __builtin_amdgcn_exp2f(p2); nb_[1] = __builtin_amdgcn_exp2f(p3);
                     na[2] = __builtin_amdgcn_exp2f(p4); nb_[2] = __builtin_amdgcn_exp2f(p5);
                     na[3] = __builtin_amdgcn_exp2f(p6); nb_[3] = __builtin_amdgcn_exp2f(p7);
                 }
-                if (tail) {
+                if (qd >= a_lo) {              // wave-uniform: some units of the first set are past their own count
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) {
-                        na[s4] = qd < nqa ? na[s4] : 0.f;
-                        nb_[s4] = qd < nqb ? nb_[s4] : 0.f;
-                    }
+                    for (int s4 = 0; s4 < 4; s4++) na[s4] = qd < nqa ? na[s4] : 0.f;
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
-                    acca = __builtin_amdgcn_mfma_f32_16x16x4f32(na[s4], bb[s4], acca, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x4f32(nb_[s4], bb[s4], accb, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        const float b = s4 == 0 ? bq[g].x : s4 == 1 ? bq[g].y : s4 == 2 ? bq[g].z : bq[g].w;
+                        acca[g] = mfma4(na[s4], b, acca[g]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        const float b = s4 == 0 ? bq[g].x : s4 == 1 ? bq[g].y : s4 == 2 ? bq[g].z : bq[g].w;
+                        accb[g] = mfma4(nb_[s4], b, accb[g]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // float64 flush every 128 diameters (8 quads), whatever the pass's length
-            for (int qo = 0; qo + 8 <= nq; qo += 8) {
-                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+            auto quad1 = [&](int qd, float nh, float nl, int nq_own, int lo, f32x4 *acc) {      // one set
+                float4 bq[NG];
 #pragma unroll
-                for (int t = 0; t < 8; t++) quad(qo + t, acca, accb);
+                for (int g = 0; g < NG; g++) bq[g] = B4[boff[g] + qd * (g == NG - 1 ? bstride_last : 4 * NC)];
+                const float4 xq = X4[qd * 4];
+                const float t = nl * xq.z;
+                float n[4] = {__builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.x, t)), __builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.y, t)),
+                              __builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.z, t)), __builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.w, t))};
+                if (qd >= lo) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
-            }
-            if (nq & 7) {
-                f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-                for (int qd = nq & ~7; qd < nq; qd++) quad(qd, acca, accb);
+                    for (int s4 = 0; s4 < 4; s4++) n[s4] = qd < nq_own ? n[s4] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) { da[r] += (double)acca[r]; db[r] += (double)accb[r]; }
+                for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+                    for (int g = 0; g < NG; g++) {
+                        const float b = s4 == 0 ? bq[g].x : s4 == 1 ? bq[g].y : s4 == 2 ? bq[g].z : bq[g].w;
+                        acc[g] = mfma4(n[s4], b, acc[g]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (n_b) {
+                for (int qd = 0; qd < a_hi; qd++) quad2(qd);
+                for (int qd = a_hi; qd < b_hi; qd++) quad1(qd, nhb, nlb, nqb, b_lo, accb);
+            } else {
+                for (int qd = 0; qd < a_hi; qd++) quad1(qd, nha, nla, nqa, a_lo, acca);
             }
         }
-        // C/D layout: column = lane & 15 (component), row = (lane >> 4) * 4 + r (unit in group)
+        // The four residues' partial sums meet (rotations by eight and by four lanes inside each row of 16 lanes, an
+        // order of additions that does not depend on the lane), then the
+        // lane with residue dr keeps register dr: unit (ug, dr) of the set, column 4 g + (lane & 3).  Result rows of
+        // 16 floats, each 16-byte piece written by four neighbouring lanes; with twelve columns the fourth piece is
+        // zeros, so that every row is written whole.
         {
+            constexpr int ROW = CPOL_N_COL;
+            auto finish = [&](int base, const f32x4 *acc) {
+                const int un = base + ug * 4 + dr;
+                if (base >= cnt) return;                 // wave-uniform: the set is empty
+                const long row = un < cnt ? (long)__float_as_int(urec[start + un].w) * ROW : 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int row = kq * 4 + r;
-                int u0 = g0 * 16 + row, u1 = u0 + 16;
-                // result rows of 16 floats (the spare columns hold zeros): one aligned 64-byte write per unit,
-                // wherever the cutoff order scattered the pass's units over the slots
-                constexpr int ROW = CPOL_N_COL;
-                if (u0 < cnt) psd_out[(long)__float_as_int(urec[start + u0].w) * ROW + comp] = (float)da[r];
-                if (u1 < cnt) psd_out[(long)__float_as_int(urec[start + u1].w) * ROW + comp] = (float)db[r];
-            }
+                for (int g = 0; g < NG; g++) {
+                    float t[4];
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        float x = acc[g][v];
+                        // (p_dr + p_dr+2) + (p_dr+1 + p_dr+3): the same value in all four lanes, whichever stores it
+                        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));      // row_ror:8
+                        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));      // row_ror:4
+                        t[v] = x;
+                    }
+                    const float val = dr == 0 ? t[0] : dr == 1 ? t[1] : dr == 2 ? t[2] : t[3];
+                    if (un < cnt) psd_out[row + 4 * g + r4] = val;
+                }
+                if (NG * 4 < ROW && un < cnt) {
+#pragma unroll
+                    for (int g = NG; g < ROW / 4; g++) psd_out[row + 4 * g + r4] = 0.f;
+                }
+            };
+            finish(u0, acca);
+            finish(u0 + 16, accb);
         }
     }
     if (work) {                                       // wave-uniform count of evaluated unit x quad steps
