@@ -582,6 +582,9 @@ def main(argv=None):
                         'avg_launch_ms': ms_int, 'flop_per_launch': flop_per_launch, 'flop_per_unit': flop_unit,
                         'launches': tim['launches']['integrate'], 'evaluated_fraction': evaluated,
                         'own_quads_fraction': (tim['own_unit_diameters'] / (1024. * tim['valid_units']) if tim['valid_units'] else None),
+                        # share of the units integrated over the seven combinations of columns the observables are made
+                        # of (8-column image) instead of all twelve components (cpol_set_column_combination)
+                        'combined_units_fraction': (tim['combined_units'] / tim['valid_units'] if tim['valid_units'] else None),
                         'algorithmic_tflops': algorithmic}
             # the two other kernels of weight, against the limits that bind them (counts from the same counter passes)
             others = []

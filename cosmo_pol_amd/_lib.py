@@ -56,7 +56,7 @@ class CpolOutputs(C.Structure):
 
 # every symbol include/cosmopol.h declares
 EXPORTS = ['cpol_create', 'cpol_destroy', 'cpol_last_error', 'cpol_stream', 'cpol_synchronize',
-           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_model_range_certified', 'cpol_set_batch_units', 'cpol_set_host_batching', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
+           'cpol_timing_enable', 'cpol_timing_read', 'cpol_timing_work', 'cpol_timing_forms', 'cpol_set_term_cutoff', 'cpol_get_term_cutoff', 'cpol_set_column_combination', 'cpol_get_column_combination', 'cpol_model_range_certified', 'cpol_set_batch_units', 'cpol_set_host_batching', 'cpol_set_config', 'cpol_set_velocity_bins', 'cpol_set_turbulence', 'cpol_set_refraction_table', 'cpol_upload_model', 'cpol_upload_lut', 'cpol_set_quadrature',
            'cpol_run_rays', 'cpol_run_rays_async', 'cpol_wait_async', 'cpol_run_rays_dev', 'cpol_run_rays_static', 'cpol_geolocate', 'cpol_interp_points',
            'cpol_observables_from_beams', 'get_all_radar_pts', 'get_refl']
 
@@ -89,10 +89,13 @@ def load():
     lib.cpol_timing_enable.argtypes = [vp, C.c_int]
     lib.cpol_timing_read.argtypes = [vp, c_double_p, C.POINTER(C.c_long), c_double_p, c_double_p]
     lib.cpol_timing_work.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+    lib.cpol_timing_forms.argtypes = [vp, c_double_p]
     lib.cpol_set_batch_units.argtypes = [vp, C.c_long]
     lib.cpol_set_host_batching.argtypes = [vp, C.c_int, C.c_double]
     lib.cpol_set_term_cutoff.argtypes = [vp, C.c_int]
     lib.cpol_get_term_cutoff.argtypes = [vp, c_float_p]
+    lib.cpol_set_column_combination.argtypes = [vp, C.c_int]
+    lib.cpol_get_column_combination.argtypes = [vp, C.POINTER(C.c_long)]
     lib.cpol_model_range_certified.argtypes = [vp]
     lib.cpol_set_config.argtypes = [vp, C.POINTER(CpolConfig)]
     lib.cpol_upload_model.argtypes = [vp, C.c_int, c_int_p, C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int,
@@ -191,9 +194,11 @@ class Context(object):
         self._check(self.lib.cpol_timing_read(self.h, ms, nl, C.byref(vu), C.byref(du)), 'cpol_timing_read')
         wk, wd, wo = C.c_double(), C.c_double(), C.c_double()
         self._check(self.lib.cpol_timing_work(self.h, C.byref(wk), C.byref(wd), C.byref(wo)), 'cpol_timing_work')
+        cu = C.c_double()
+        self._check(self.lib.cpol_timing_forms(self.h, C.byref(cu)), 'cpol_timing_forms')
         return {'ms': dict(zip(self.STAGES, list(ms))), 'launches': dict(zip(self.STAGES, list(nl))),
                 'valid_units': vu.value, 'doppler_units': du.value, 'evaluated_unit_diameters': wk.value,
-                'doppler_unit_diameters': wd.value, 'own_unit_diameters': wo.value}
+                'doppler_unit_diameters': wd.value, 'own_unit_diameters': wo.value, 'combined_units': cu.value}
 
     def set_term_cutoff(self, certified=True):
         self._check(self.lib.cpol_set_term_cutoff(self.h, int(bool(certified))), 'cpol_set_term_cutoff')
@@ -204,6 +209,18 @@ class Context(object):
         e = (C.c_float * 4)()
         self._check(self.lib.cpol_get_term_cutoff(self.h, e), 'cpol_get_term_cutoff')
         return {k: float(e[i]) for k, i in CLASS_INDEX.items() if e[i] > 0}
+
+    def set_column_combination(self, on=True):
+        """Integrate the units over the seven combinations of columns the observables are made of where that cannot
+        change what the reference's rules about zero and underflowing components yield (see cosmopol.h); on=False: all
+        units over all twelve columns."""
+        self._check(self.lib.cpol_set_column_combination(self.h, int(bool(on))), 'cpol_set_column_combination')
+
+    def get_column_combination(self):
+        """{class letter: number of table nodes whose units may take the combined columns}; empty when none does."""
+        f = (C.c_long * 8)()
+        self._check(self.lib.cpol_get_column_combination(self.h, f), 'cpol_get_column_combination')
+        return {k: int(f[i]) for k, i in CLASS_INDEX.items() if f[i] > 0}
 
     def model_range_certified(self):
         """True when the uploaded model's values let the vertical interpolation share one reciprocal per level pair

@@ -80,8 +80,9 @@ static void timing_collect(cpol_ctx *ctx)
     ctx->spans.clear();
     ctx->ev_used = 0;
     for (size_t i = 0; i < ctx->valid_used; i++) {
-        ctx->valid_units += ctx->valid_host[2 * i];
-        ctx->dop_units += ctx->valid_host[2 * i + 1] - ctx->valid_host[2 * i];
+        ctx->valid_units += ctx->valid_host[3 * i];
+        ctx->dop_units += ctx->valid_host[3 * i + 1] - ctx->valid_host[3 * i];
+        ctx->comb_units += ctx->valid_host[3 * i + 2];
     }
     ctx->valid_used = 0;
 }
@@ -97,7 +98,7 @@ extern "C" int cpol_timing_enable(cpol_ctx *ctx, int on)
     if (ctx->work_dev) HIPCHK(ctx, hipMemset(ctx->work_dev, 0, work_bytes));
     ctx->timing = on != 0;
     for (int i = 0; i < CPOL_N_STAGES; i++) { ctx->stage_ms[i] = 0; ctx->stage_launches[i] = 0; }
-    ctx->valid_units = 0; ctx->dop_units = 0;
+    ctx->valid_units = 0; ctx->dop_units = 0; ctx->comb_units = 0;
     return CPOL_OK;
 }
 
@@ -138,6 +139,16 @@ extern "C" int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters,
     return CPOL_OK;
 }
 
+extern "C" int cpol_timing_forms(cpol_ctx *ctx, double *combined_units)
+{
+    if (!ctx || !combined_units) return CPOL_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    timing_collect(ctx);
+    *combined_units = ctx->comb_units;
+    return CPOL_OK;
+}
+
 extern "C" int cpol_set_term_cutoff(cpol_ctx *ctx, int certified)
 {
     if (!ctx) return CPOL_ERR_ARG;
@@ -153,6 +164,40 @@ extern "C" int cpol_set_term_cutoff(cpol_ctx *ctx, int certified)
             return build_class_table(ctx, ct, true);
         }
     }
+    return CPOL_OK;
+}
+
+extern "C" int cpol_set_column_combination(cpol_ctx *ctx, int on)
+{
+    if (!ctx) return CPOL_ERR_ARG;
+    ctx->combine_columns = on != 0;
+    for (auto &l : ctx->lut) l.image_ncol = 0;          // images are redone at the next set-up / run
+    if (ctx->have_cfg) {
+        bool all = true;
+        const int n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
+        for (int h = 0; h < n_cls; h++) all = all && ctx->lut[h].present;
+        if (all) {
+            HIPCHK(ctx, hipSetDevice(ctx->device));
+            ClassTable ct;
+            return build_class_table(ctx, ct, true);
+        }
+    }
+    return CPOL_OK;
+}
+
+extern "C" int cpol_get_column_combination(cpol_ctx *ctx, long nodes_per_class[CPOL_MAX_CLASSES])
+{
+    if (!ctx || !nodes_per_class) return CPOL_ERR_ARG;
+    for (int h = 0; h < CPOL_MAX_CLASSES; h++) nodes_per_class[h] = 0;
+    if (!ctx->have_cfg) return CPOL_OK;
+    const int n_cls = ctx->cfg.microphysics_scheme == 1 ? 3 : 4;
+    for (int h = 0; h < n_cls; h++)
+        if (!ctx->lut[h].present) return CPOL_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ClassTable ct;
+    TRY(build_class_table(ctx, ct, true));
+    if (ct.comb)
+        for (int h = 0; h < n_cls; h++) nodes_per_class[h] = ctx->lut[h].nodes_comb;
     return CPOL_OK;
 }
 
@@ -246,7 +291,7 @@ extern "C" int cpol_destroy(cpol_ctx *ctx)
     if (ctx->refr_tab) (void)hipFree(ctx->refr_tab);
     if (ctx->rawptr_dev) (void)hipFree((void *)ctx->rawptr_dev);
     for (auto &l : ctx->lut) {
-        float *owned[] = {l.raw, l.rcs, l.table, l.xq, l.table_dop, l.xq_dop, l.d_axis};
+        float *owned[] = {l.raw, l.rcs, l.table, l.table_comb, l.node_floor, l.xq, l.table_dop, l.xq_dop, l.d_axis};
         for (float *q : owned) if (q) (void)hipFree(q);
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -387,7 +432,7 @@ extern "C" int cpol_upload_lut(cpol_ctx *ctx, int cls, const cpol_lut *lut, cons
         return fail(ctx, CPOL_ERR_ARG, "bad psd descriptor");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     LutDev &L = ctx->lut[cls];
-    float **owned[] = {&L.raw, &L.rcs, &L.table, &L.xq, &L.table_dop, &L.xq_dop, &L.d_axis};
+    float **owned[] = {&L.raw, &L.rcs, &L.table, &L.table_comb, &L.node_floor, &L.xq, &L.table_dop, &L.xq_dop, &L.d_axis};
     for (float **q : owned) if (*q) { HIPCHK(ctx, hipFree(*q)); }
     L = LutDev();
     size_t nt = (size_t)lut->n_e * lut->n_t * lut->n_d * CPOL_N_SZ;
@@ -515,18 +560,22 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
     ct.dop_shared = shared ? 1 : 0;
     ct.ncol = shared ? 14 : 12;
     ct.n_kinds = (dop2 && !shared) ? 2 : 1;
+    // the combined columns (ClassTable::comb) hold the polarimetric quantities only
+    const bool want_comb = ctx->combine_columns && !shared;
     for (int h = 0; h < ct.n_cls; h++) {
         LutDev &L = ctx->lut[h];
         const long nslice = (long)L.n_e * L.n_t;
         const size_t img_bytes = (size_t)nslice * 1024 * ct.ncol * sizeof(float);
         const int want_dop_img = ct.n_kinds == 2 ? 1 : 0;
-        const int tag = ct.ncol * 4 + (shared ? 2 : 0) + want_dop_img;
+        const int tag = ct.ncol * 4 + (shared ? 2 : 0) + want_dop_img + (want_comb ? 256 : 0);
         if (L.image_ncol != tag) {
             if (!allow_build)
                 return fail(ctx, CPOL_ERR_STATE, "the lookup-table images of this configuration have not been built yet: "
                                                  "call cpol_set_config and cpol_upload_lut (which build them) first");
             if (L.table) { HIPCHK(ctx, hipFree(L.table)); L.table = nullptr; }
             if (L.table_dop) { HIPCHK(ctx, hipFree(L.table_dop)); L.table_dop = nullptr; }
+            if (L.table_comb) { HIPCHK(ctx, hipFree(L.table_comb)); L.table_comb = nullptr; }
+            if (L.node_floor) { HIPCHK(ctx, hipFree(L.node_floor)); L.node_floor = nullptr; }
             if (!L.xq) HIPCHK(ctx, hipMalloc((void **)&L.xq, 1024 * sizeof(float)));
             if (!L.xq_dop) HIPCHK(ctx, hipMalloc((void **)&L.xq_dop, 1024 * sizeof(float)));
             HIPCHK(ctx, hipMalloc((void **)&L.table, img_bytes));
@@ -537,6 +586,19 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
                 launch_build_dop_image(ctx->stream, L.raw, L.d_axis, L.table_dop, L.xq_dop, nslice, L.psd_dop.mu,
                                        L.psd_dop.nu, L.psd_dop.alpha, L.psd_dop.beta, (double)(float)xref_of(L, L.psd_dop.nu));
             }
+            if (!ctx->cert_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->cert_dev, 4 * sizeof(float)));
+            L.nodes_comb = 0;
+            if (want_comb) {
+                HIPCHK(ctx, hipMalloc((void **)&L.table_comb, (size_t)nslice * 1024 * CPOL_N_COMB * sizeof(float)));
+                HIPCHK(ctx, hipMalloc((void **)&L.node_floor, (size_t)nslice * sizeof(float)));
+                launch_build_image(ctx->stream, L.raw, L.d_axis, L.table_comb, L.xq, nslice, CPOL_N_COMB, L.psd.mu, L.psd.nu,
+                                   0, 0, 0., 0., 0., xref_of(L, L.psd.nu));
+                launch_node_floor(ctx->stream, L.raw, L.d_axis, nslice, L.psd.mu, L.node_floor);
+                std::vector<float> fl((size_t)nslice);
+                HIPCHK(ctx, hipMemcpyAsync(fl.data(), L.node_floor, fl.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                for (float f : fl) L.nodes_comb += f > 0.f ? 1 : 0;
+            }
             HIPCHK(ctx, hipGetLastError());
             // term cutoff of the class: the smallest exponent its tables are certified for, else exact zeros only
             L.cut_e = 152.f;
@@ -545,7 +607,6 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
                 bool asc = L.d_host.size() == 1024 && L.d_host[0] > 0.f;
                 for (int d = 1; asc && d < 1024; d++) asc = L.d_host[d] > L.d_host[d - 1];
                 const double cand[] = {48., 56., 64., 72., 80., 96., 112., 128.};
-                if (ctx->certified_cutoff && asc && !ctx->cert_dev) HIPCHK(ctx, hipMalloc((void **)&ctx->cert_dev, sizeof(float)));
                 if (ctx->certified_cutoff && asc && L.psd.nu > 0.) {
                     for (double e : cand) {
                         const float worst = cut_certificate(ctx->stream, L.raw, L.d_axis, nslice, L.psd.mu, L.psd.nu,
@@ -571,6 +632,8 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
         v.e_min = L.e_min; v.e_step = L.e_step; v.t_min = L.t_min; v.t_step = L.t_step; v.dD = L.dD;
         ct.lut_dop[h] = v;
         ct.lut_dop[h].table = L.table_dop; ct.lut_dop[h].xq = L.xq_dop;
+        ct.lut_comb[h] = v;
+        ct.lut_comb[h].table = L.table_comb; ct.lut_comb[h].floor = L.node_floor;
         // exp(-lambda D) over equally spaced D is a geometric sequence: k_integrate_dop then needs one
         // exponential per 64 diameters
         ct.pol_x0[h] = xref_of(L, L.psd.nu);
@@ -589,7 +652,14 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
         if (L.n_e > ct.ne_max) ct.ne_max = L.n_e;
         if (L.n_t > ct.nt_max) ct.nt_max = L.n_t;
     }
-    if ((long)ct.n_kinds * ct.n_cls * ct.ne_max * ct.nt_max > 16384) return fail(ctx, CPOL_ERR_ARG, "more than 16384 lookup-table nodes");
+    // two forms of polarimetric unit when any node qualifies for the combined columns
+    bool any = false;
+    for (int h = 0; h < ct.n_cls; h++) any = any || (want_comb && ctx->lut[h].table_comb && ctx->lut[h].nodes_comb > 0);
+    const long pol_nodes = (long)ct.n_cls * ct.ne_max * ct.nt_max;
+    ct.comb = (any && 2 * pol_nodes <= 32767) ? 1 : 0;
+    ct.n_pol_planes = ct.n_cls * (1 + ct.comb);
+    if (pol_nodes * (1 + ct.comb) > 32767)
+        return fail(ctx, CPOL_ERR_ARG, "more than 32767 lookup-table nodes (class x elevation x temperature)");
     return CPOL_OK;
 }
 
@@ -629,14 +699,17 @@ static int ensure_physics(cpol_ctx *ctx, const ClassTable &ct, long nu)
 {
     const int n_planes = ct.n_kinds * ct.n_cls;
     const long nslots = nu * n_planes;
-    const int nb = n_planes * ct.ne_max * ct.nt_max;
+    const int nb = ct.n_kinds * ct.n_pol_planes * ct.ne_max * ct.nt_max;
     TRY(ensure(ctx, ctx->w->b_key, nslots * sizeof(cpol_key_t)));
     TRY(ensure(ctx, ctx->w->b_lam, nslots * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_coef, nslots * sizeof(double)));
     TRY(ensure(ctx, ctx->w->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
     TRY(ensure(ctx, ctx->w->b_urec, (size_t)nu * ct.n_cls * sizeof(float4)));          // the chunks' units in cutoff order
     TRY(ensure(ctx, ctx->w->b_rank, nslots * sizeof(int)));
-    TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * CPOL_N_COL * sizeof(float)));      // polarimetric units only
+    // result rows of the polarimetric units: 16 floats, or with combined columns 8 and, for the units that take all
+    // twelve columns, 4 more beside them
+    TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * (ct.comb ? CPOL_N_COMB : CPOL_N_COL) * sizeof(float)));
+    if (ct.comb) TRY(ensure(ctx, ctx->w->b_psd_hi, (size_t)nu * ct.n_cls * 4 * sizeof(float)));
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->w->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_cbkt, (size_t)((nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb + 1) * sizeof(int)));
     TRY(ensure(ctx, ctx->w->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
@@ -648,7 +721,7 @@ static int ensure_physics(cpol_ctx *ctx, const ClassTable &ct, long nu)
 // Clear the (bucket, shard) counters that the PSD set-up fills.
 static int clear_hist(cpol_ctx *ctx, const ClassTable &ct)
 {
-    const int nb = ct.n_kinds * ct.n_cls * ct.ne_max * ct.nt_max;
+    const int nb = ct.n_kinds * ct.n_pol_planes * ct.ne_max * ct.nt_max;
     HIPCHK(ctx, hipMemsetAsync(ctx->w->b_hist.p, 0, (size_t)CPOL_SORT_SHARDS * (nb + 1) * sizeof(int), ctx->stream));
     return CPOL_OK;
 }
@@ -662,10 +735,8 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
                        bool prepped = false)
 {
     const long nu = (long)nr * B * G;
-    const int n_planes = ct.n_kinds * ct.n_cls;
-    const long nslots = nu * n_planes;
-    const int nb = n_planes * ct.ne_max * ct.nt_max;
-    const int nb_pol = ct.n_cls * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
+    const int nb = ct.n_kinds * ct.n_pol_planes * ct.ne_max * ct.nt_max;
+    const int nb_pol = ct.n_pol_planes * ct.ne_max * ct.nt_max;       // the separate Doppler units' buckets follow
     TRY(ensure_physics(ctx, ct, nu));
     int *hist = (int *)ctx->w->b_hist.p, *cursor = hist + CPOL_SORT_SHARDS * (nb + 1), *offs = cursor + CPOL_SORT_SHARDS * (nb + 1),
         *chunk_off = offs + (nb + 1);
@@ -673,7 +744,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     StageTimer t_(ctx, CPOL_ST_PREP_SORT);
     if (!prepped) {
         TRY(clear_hist(ctx, ct));
-        launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, mask, wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
+        launch_prep(ctx->stream, ct, nu, G, vals, plane, elev, const_cast<signed char *>(mask), wsub, B, phi, ctx->cfg.doppler_scheme == 3 ? 0 : ctx->cfg.doppler_scheme,
                     (cpol_key_t *)ctx->w->b_key.p, (int *)ctx->w->b_rank.p, (float2 *)ctx->w->b_lam.p, (double *)ctx->w->b_coef.p,
                     (double *)ctx->w->b_n0d.p, hist, (double *)ctx->w->b_vr.p);
     } else if (ctx->cfg.doppler_scheme == 1)
@@ -689,20 +760,24 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             timing_collect(ctx);
             if (!ctx->valid_host) {
-                HIPCHK(ctx, hipHostMalloc((void **)&ctx->valid_host, 2 * 4096 * sizeof(int), hipHostMallocDefault));
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->valid_host, 3 * 4096 * sizeof(int), hipHostMallocDefault));
                 ctx->valid_cap = 4096;
             }
         }
-        int *vh = ctx->valid_host + 2 * ctx->valid_used++;
+        int *vh = ctx->valid_host + 3 * ctx->valid_used++;
         HIPCHK(ctx, hipMemcpyAsync(vh, offs + nb_pol, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(vh + 1, offs + nb, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        // units in the combined form: the buckets of the planes [0, n_cls) when there are two forms
+        vh[2] = 0;
+        if (ct.comb) HIPCHK(ctx, hipMemcpyAsync(vh + 2, offs + ct.n_cls * ct.ne_max * ct.nt_max, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     }
     // upper bound of the chunk count of either kind (the exact count lives on the device)
     const long max_chunks = (nu * ct.n_cls + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb_pol;
     {
     StageTimer t_(ctx, CPOL_ST_INTEGRATE);
     launch_integrate(ctx->stream, ct, max_chunks, nb_pol, offs, chunk_off, (const int *)ctx->w->b_cbkt.p, (const int *)ctx->w->b_sorted.p,
-                     (float4 *)ctx->w->b_urec.p, (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, count_work ? ctx->work_dev : nullptr);
+                     (float4 *)ctx->w->b_urec.p, (const float2 *)ctx->w->b_lam.p, (float *)ctx->w->b_psd.p, (float *)ctx->w->b_psd_hi.p,
+                     count_work ? ctx->work_dev : nullptr);
     }
     if (ct.n_kinds == 2) {
         StageTimer t_(ctx, CPOL_ST_INTEGRATE_DOP);
@@ -712,7 +787,9 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     }
     ObsParams op;
     build_obs_params(ctx, B, G, ct.n_cls, op);
-    op.row = CPOL_N_COL;
+    op.row = ct.comb ? CPOL_N_COMB : CPOL_N_COL;
+    op.comb = ct.comb;
+    op.nb_form = ct.n_cls * ct.ne_max * ct.nt_max;
     Dop2In d2;
     memset(&d2, 0, sizeof(d2));
     if (ctx->cfg.doppler_scheme == 2) {
@@ -781,7 +858,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     }
     StageTimer t_(ctx, CPOL_ST_OBSERVABLES);
     launch_observables(ctx->stream, op, nr, nu, (const cpol_key_t *)ctx->w->b_key.p, (const double *)ctx->w->b_coef.p,
-                       (const float *)ctx->w->b_psd.p, mask, wsub, (const double *)ctx->w->b_vr.p, obs, obs_plane, ray0,
+                       (const float *)ctx->w->b_psd.p, (const float *)ctx->w->b_psd_hi.p, mask, wsub, (const double *)ctx->w->b_vr.p, obs, obs_plane, ray0,
                        mask_out, rvel_out, d2, spectrum, ctx->n_vel);
     HIPCHK(ctx, hipGetLastError());
     return CPOL_OK;

@@ -16,7 +16,9 @@ typedef short cpol_key_t;         // bucket (class, elevation node, temperature 
 // of a launch spread their atomics over many lines
 #define CPOL_WORK_SLOTS 1024
 #define CPOL_WORK_STRIDE 8
-#define CPOL_N_COL 16             // MFMA N dimension: 12 scattering components + 4 spare columns
+#define CPOL_N_COL 16             // floats per result row of a unit integrated over all columns: 12 scattering components (+ 2 Doppler moments) + spare
+#define CPOL_MASK_COMB 4          // interpolation code (-1, 0, 1) of a point inside the model one of whose units takes the combined columns
+#define CPOL_N_COMB 8             // columns of the combined image = floats per result row of a unit integrated over it: 7 combinations + a spare
 
 struct LutDev {
     bool   present = false;
@@ -26,6 +28,9 @@ struct LutDev {
     float *raw = nullptr;          // [n_e][n_t][1024][12] as uploaded
     float *rcs = nullptr;          // [n_e][n_t][1024] radar cross-section 2 pi (z0 - z1 - z2 + z3), built for the Doppler spectrum
     float *table = nullptr;        // [n_e][n_t] slices of 1024 x ncol, permuted and pre-multiplied by D^mu (see k_integrate)
+    float *table_comb = nullptr;   // the same for the eight combined columns (see k_build_image), built when the configuration uses them
+    float *node_floor = nullptr;   // [n_e][n_t]: smallest first-diameter term of the node's columns, 0 where a column changes sign (k_node_floor)
+    long   nodes_comb = 0;         // nodes with a positive floor
     float *xq = nullptr;           // D^nu, permuted for the integrate kernel's ds_read_b128
     float *table_dop = nullptr;    // compact 3-column image of the separate Doppler units (k_integrate_dop)
     float *xq_dop = nullptr;
@@ -44,6 +49,7 @@ struct LutDev {
 struct LutView {
     const float *table;
     const float *xq;
+    const float *floor;            // per node, see LutDev::node_floor (views of the combined image only)
     int   n_e, n_t, n_d;
     float e_min, e_step, t_min, t_step;
     float dD;
@@ -69,6 +75,14 @@ struct ClassTable {
     int     ncol;                  // columns of the polarimetric image: 12, or 14 when the two Doppler scheme-2
                                    // moments ride on the polarimetric units (dop_shared)
     int     dop_shared;            // Doppler moments ride on the polarimetric units (identical PSD)
+    // Two forms of polarimetric unit when comb = 1: planes [0, n_cls) are integrated over the seven combinations of
+    // columns the observables are made of (lut_comb, 8 columns), planes [n_cls, 2 n_cls) over all twelve columns (lut).
+    // A unit takes the first form when its contribution to every one of the twelve components is certain to be a
+    // normal float32: every column of its node has one sign along the diameter axis and
+    // coef * lut_comb[h].floor[node] >= 2^-100.
+    int     comb;
+    int     n_pol_planes;          // n_cls * (1 + comb)
+    LutView lut_comb[CPOL_MAX_CLASSES];
     LutView lut[CPOL_MAX_CLASSES];
     LutView lut_dop[CPOL_MAX_CLASSES];
     double  pol_x0[CPOL_MAX_CLASSES];         // D_0^nu of the polarimetric PSD
@@ -112,7 +126,8 @@ struct ObsParams {
     float  res, res_km;            // radial resolution and resolution / 1000 as float32 operands
     float  two_pi, zfac, kdpfac, two_wl, afac;
     int    att_corr, doppler, sens_mode;
-    int    row;                    // floats per result row of the PSD integration (12, or 16 with Doppler columns)
+    int    row;                    // floats per result row of the PSD integration: 16, or 8 with combined columns
+    int    comb, nb_form;          // combined columns in use; keys from nb_form on are units in the twelve-column form
     double sens0, sens1, res_d;
 };
 
@@ -151,7 +166,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     struct Work {
         Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-            b_sorted, b_urec, b_rank, b_psd, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+            b_sorted, b_urec, b_rank, b_psd, b_psd_hi, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
             o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, o_diag, t_a, t_b, t_c, t_d, t_e;
     };
     Work heap, arena_work;
@@ -169,6 +184,7 @@ struct cpol_ctx {
     int async_slot = 0;
     // optional stage timing (hipEvents on ctx->stream) and work counters
     bool   certified_cutoff = true;               // term cutoffs below the exact-zero one where the tables carry a certificate
+    bool   combine_columns = true;                // integrate the combinations of columns the observables use where that is safe (ClassTable::comb)
     float *cert_dev = nullptr;                    // result word of k_cut_certificate
     unsigned long long *work_dev = nullptr;       // 3 x CPOL_WORK_SLOTS partial counts of unit x 16-diameter steps: evaluated by k_integrate, by k_integrate_dop, and the units' own counts in k_integrate (timing only)
     bool timing = false;
@@ -180,7 +196,7 @@ struct cpol_ctx {
     long   stage_launches[CPOL_N_STAGES] = {0};
     int   *valid_host = nullptr;                  // pinned: valid units of each batch
     size_t valid_cap = 0, valid_used = 0;
-    double valid_units = 0, dop_units = 0;
+    double valid_units = 0, dop_units = 0, comb_units = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                  \
@@ -201,12 +217,13 @@ void launch_geom(hipStream_t s, const GeomParams &gp, int n_rays, const double *
 void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coords, const float *H,
                    float *vals, long plane, signed char *mask, float *raw_out);
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
-                 const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
+                 const float *elev, signed char *mask, const double *weight_per_sub, int n_sub,
                  const double *phi_sc, int doppler, cpol_key_t *key, int *rank, float2 *lam, double *coef, double *n0d,
                  int *hist, double *vr);
 void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, float *img, float *xq, long nslice,
                         int ncol, double mu, double nu, int with_dop, int zero_pol, double mu_d, double alpha_d,
                         double beta_d, double x_ref);
+void launch_node_floor(hipStream_t s, const float *raw, const float *d_axis, long nslice, double mu, float *floor_out);
 void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
                  int *chunk_bucket);
@@ -214,7 +231,7 @@ void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, co
                     const int *cursor, int *sorted);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, float4 *urec, const float2 *lam,
-                      float *psd_out, unsigned long long *work);
+                      float *psd_out, float *psd_hi, unsigned long long *work);
 float cut_certificate(hipStream_t s, const float *raw, const float *d_axis, long nslice, double mu, double nu, double x_ref,
                       int with_dop, double mu_d, double alpha_d, double beta_d, double cut_e, float *worst_dev);
 void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, int b_lo, int b_hi, const int *offs,
@@ -275,7 +292,7 @@ void launch_front(hipStream_t s, const GeomParams &gp, const ModelView &mv, cons
 void launch_vr1(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
                 const float *elev, const double *phi_sc, double *vr);
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const cpol_key_t *key,
-                        const double *coef, const float *psd_out, const signed char *mask,
+                        const double *coef, const float *psd_out, const float *psd_hi, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel);
 struct DiagVars { int n; int var[CPOL_MAX_VARS]; };      // uploaded variables in upload order -> cpol_var slot

@@ -764,6 +764,8 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
 //   B'[d][j <  12] = sz[d][j] * D^mu                       (scattering_sz.py:95-103, PSD weight folded in)
 //   B'[d][12]      = rcs[d] * D^mu_d,  B'[d][13] = rcs[d] * v(D) * D^mu_d     (doppler_sz.py:192,218-220)
 // with rcs = 2 pi (sz0 - sz1 - sz2 + sz3) and v = alpha D^beta in float32 as in the reference.
+// ncol = CPOL_N_COMB (8): the image of the combined columns instead,
+//   B'[d][0..6] = (h, v, s4 + s7, s6 - s5, s10 - s8, s11, s9)[d] * D^mu,  B'[d][7] = 0.
 // xq[(q*4 + k)*4 + s] = D^nu - D_0^nu in the same permuted order.
 // =============================================================================
 __global__ void k_build_image(const float *__restrict__ raw, const float *__restrict__ d_axis, float *__restrict__ img,
@@ -779,7 +781,15 @@ __global__ void k_build_image(const float *__restrict__ raw, const float *__rest
     float D = d_axis[d];
     const float *src = raw + (sl * 1024 + d) * CPOL_N_SZ;
     float val;
-    if (j < CPOL_N_SZ) val = zero_pol ? 0.f : src[j] * (float)pow((double)D, mu);
+    if (ncol == CPOL_N_COMB) {
+        // the combinations of columns the observables are made of (scattering_sz.py:168-194), formed in float64 from the
+        // table's float32 entries and rounded once: h, v, s4 + s7, s6 - s5, s10 - s8, s11, s9, and a spare column
+        const double z[CPOL_N_SZ] = {src[0], src[1], src[2], src[3], src[4], src[5], src[6], src[7], src[8], src[9], src[10], src[11]};
+        const double g = j == 0 ? ((z[0] - z[1]) - z[2]) + z[3] : j == 1 ? ((z[0] + z[1]) + z[2]) + z[3] : j == 2 ? z[4] + z[7]
+                       : j == 3 ? z[6] - z[5] : j == 4 ? z[10] - z[8] : j == 5 ? z[11] : j == 6 ? z[9] : 0.;
+        val = (float)(g * pow((double)D, mu));
+    }
+    else if (j < CPOL_N_SZ) val = zero_pol ? 0.f : src[j] * (float)pow((double)D, mu);
     else if (!with_dop) val = 0.f;
     else {
         float rcs = (float)(2 * M_PI) * (((src[0] - src[1]) - src[2]) + src[3]);
@@ -788,7 +798,8 @@ __global__ void k_build_image(const float *__restrict__ raw, const float *__rest
         if (j == 13) val = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * xm;
     }
     int q = d >> 4, s4 = (d >> 2) & 3, k = d & 3;
-    img[sl * 1024 * ncol + (((long)(q * 4 + k) * ncol + j) << 2) + s4] = val;
+    const int jw = (ncol == CPOL_N_COMB && (k & 2)) ? j ^ 4 : j;      // word of the column inside its row of the image
+    img[sl * 1024 * ncol + (((long)(q * 4 + k) * ncol + jw) << 2) + s4] = val;
     // exponent argument relative to x_ref = the smallest D^nu of the axis (the first diameter of the reference's
     // tables): k_prep folds exp(-lambda x_ref) into the unit's coefficient in float64, so the float32 sums keep
     // their leading terms however large lambda is
@@ -802,6 +813,43 @@ void launch_build_image(hipStream_t s, const float *raw, const float *d_axis, fl
     long total = nslice * 1024 * ncol;
     hipLaunchKernelGGL(k_build_image, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, raw, d_axis, img, xq, nslice,
                        ncol, mu, nu, with_dop, zero_pol, mu_d, alpha_d, beta_d, x_ref);
+}
+
+// The scale of a table node's first-diameter terms: floor[node] = the smallest |sz[node][first diameter][k]| D_0^mu
+// over the twelve columns, or 0 when one of them is zero there or the node holds a NaN anywhere.  In the integration
+// kernels the first diameter's N(D) factor is exactly 1, so a unit's coefficient times this number is the size of the
+// smallest leading term among its twelve sums; a column that keeps one sign along the diameter axis has a sum at least
+// that large.  One workgroup per node.
+__global__ __launch_bounds__(256)
+void k_node_floor(const float *__restrict__ raw, const float *__restrict__ d_axis, double mu, float *__restrict__ floor_out)
+{
+    __shared__ int s_bad[4];
+    const long sl = blockIdx.x;
+    int bad = 0;
+    for (int d = threadIdx.x; d < 1024; d += 256) {
+        const float *src = raw + (sl * 1024 + d) * CPOL_N_SZ;
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) bad |= src[k] != src[k];
+    }
+    bad = __any(bad);
+    if ((threadIdx.x & 63) == 0) s_bad[threadIdx.x >> 6] = bad;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float fl = 0.f;
+        if (!(s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3])) {
+            const float dm = (float)pow((double)d_axis[0], mu);
+            const float *src = raw + sl * 1024 * CPOL_N_SZ;
+            fl = __builtin_inff();
+            for (int k = 0; k < CPOL_N_SZ; k++) fl = fminf(fl, fabsf(src[k] * dm));
+            if (!(fl > 0.f) || !(fl < __builtin_inff())) fl = 0.f;
+        }
+        floor_out[sl] = fl;
+    }
+}
+
+void launch_node_floor(hipStream_t s, const float *raw, const float *d_axis, long nslice, double mu, float *floor_out)
+{
+    hipLaunchKernelGGL(k_node_floor, dim3((unsigned)nslice), dim3(256), 0, s, raw, d_axis, mu, floor_out);
 }
 
 // Certificate for a term cutoff below the exact-zero one.  A unit with slope l2 leaves out the quads whose first
@@ -1153,13 +1201,15 @@ __device__ inline double doppler1_radial(const ClassTable &ct, const float *__re
 // PSD set-up of one point for every class: table node (bucket key), lambda, float64 coefficients, and the point's
 // position inside its (bucket, shard) counter.  val(v) returns the point's model variable v; the 64 lanes of a wave
 // hold 64 consecutive points.
+// Returns whether one of the point's units takes the combined columns.
 template <class ValFn>
-__device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool live, int lane, float T, float e_raw,
+__device__ inline bool prep_classes(const ClassTable &ct, long nu, long u, bool live, int lane, float T, float e_raw,
                                     double w, int doppler, ValFn val, cpol_key_t *__restrict__ key,
                                     int *__restrict__ rank, float2 *__restrict__ lam, double *__restrict__ coef,
                                     double *__restrict__ n0d, int *__restrict__ hist)
 {
     const float e = fold_elev(e_raw);
+    bool any_comb = false;
     for (int h = 0; h < ct.n_cls; h++) {
         const PsdView &p = ct.psd[h];
         const LutView &lv = ct.lut[h];
@@ -1174,15 +1224,23 @@ __device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool 
         if (valid) {
             int ie = nearest_node(e, lv.e_min, lv.e_step, lv.n_e);
             int it = nearest_node(T, lv.t_min, lv.t_step, lv.n_t);
-            k = (h * ct.ne_max + ie) * ct.nt_max + it;
             // the integration works with exp(-lambda (D^nu - D_0^nu)): the factor of the first diameter goes
             // into the float64 coefficients
             double l2, nf;
             psd_fast(p, q, qn, T, ct.pol_x0[h], &l2, &nf);
             float hi = (float)l2;
             lam[(long)h * nu + u] = make_float2(hi, (float)(l2 - (double)hi));
-            coef[(long)h * nu + u] = nf * (double)lv.dD * w;
+            const double c = nf * (double)lv.dD * w;
+            coef[(long)h * nu + u] = c;
             if (doppler == 2 && ct.dop_shared) n0d[(long)h * nu + u] = nf;
+            // form of the unit (ClassTable::comb): the combined columns when c times the smallest first-diameter term of
+            // its node - the scale of its smallest contribution to any of the twelve components - is a normal float32
+            // far from the subnormals; else (also for c that is not a number, or a node with a zero or NaN entry) all
+            // twelve columns, treated as the reference treats them
+            const bool combined = ct.comb && c * (double)ct.lut_comb[h].floor[ie * lv.n_t + it] >= 0x1p-100;
+            any_comb = any_comb || combined;
+            const int plane = combined ? h : (ct.comb ? ct.n_cls + h : h);
+            k = (plane * ct.ne_max + ie) * ct.nt_max + it;
         }
         if (live) key[(long)h * nu + u] = (cpol_key_t)k;
         // position of the unit inside its (bucket, shard) counter: one atomic per run of equal keys
@@ -1212,10 +1270,11 @@ __device__ inline void prep_classes(const ClassTable &ct, long nu, long u, bool 
             // k_scan_shards and k_scatter reuse the polarimetric counters, no second round of atomics
         }
     }
+    return any_comb;
 }
 
 __global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_gates, const float *__restrict__ vals, long plane,
-                       const float *__restrict__ elev, const signed char *__restrict__ /*mask: invalid gates carry NaN*/,
+                       const float *__restrict__ elev, signed char *__restrict__ mask /* invalid gates carry NaN; gains the code CPOL_MASK_COMB */,
                        const double *__restrict__ wsub, int n_sub, const double *__restrict__ phi_sc, int doppler,
                        cpol_key_t *__restrict__ key, int *__restrict__ rank, float2 *__restrict__ lam,
                        double *__restrict__ coef, double *__restrict__ n0d, int *__restrict__ hist,
@@ -1229,8 +1288,9 @@ __global__ __launch_bounds__(256, 6) void k_prep(ClassTable ct, long nu, int n_g
     int b = (int)(rb % n_sub);
     float T = vals[(long)CPOL_V_T * plane + uu];
     float e_raw = elev[uu];
-    prep_classes(ct, nu, u, live, lane, T, e_raw, wsub[b], doppler,
-                 [&](int v) { return vals[(long)v * plane + uu]; }, key, rank, lam, coef, n0d, hist);
+    const bool any_comb = prep_classes(ct, nu, u, live, lane, T, e_raw, wsub[b], doppler,
+                                       [&](int v) { return vals[(long)v * plane + uu]; }, key, rank, lam, coef, n0d, hist);
+    if (live && any_comb && mask[u] == 0) mask[u] = CPOL_MASK_COMB;
     if (doppler == 1 && live) vr[u] = doppler1_radial(ct, vals, plane, uu, rb, n_gates, e_raw, phi_sc);
 }
 
@@ -1290,15 +1350,17 @@ void k_front(GeomParams gp, ModelView mv, ClassTable ct, long nu, const double *
     const float qnan = __builtin_nanf("");
     const float *rec = s_rec[wv][lane];
     if (live) {
-        fo.mask[u] = (signed char)code;
         for (int v = 0; v < mv.nv; v++) {
             const int var = mv.var_of_slot[v];
             if ((fo.write_mask >> var) & 1u) fo.vals[(long)var * fo.plane + u] = code == 0 ? rec[v] : qnan;
         }
     }
     auto val = [&](int v) { return code == 0 ? rec[mv.slot_of_var[v]] : qnan; };
-    prep_classes(ct, nu, u, live, lane, val(CPOL_V_T), p.E, w_sub, doppler, val, fo.key, fo.rank, fo.lam, fo.coef,
-                 fo.n0d, fo.hist);
+    const bool any_comb = prep_classes(ct, nu, u, live, lane, val(CPOL_V_T), p.E, w_sub, doppler, val, fo.key, fo.rank,
+                                       fo.lam, fo.coef, fo.n0d, fo.hist);
+    // interpolation code of the point; a point inside the model (code 0) that holds a unit in the combined form carries
+    // CPOL_MASK_COMB instead, so that the reduction of its gate knows without looking at the units
+    if (live) fo.mask[u] = (signed char)((code == 0 && any_comb) ? CPOL_MASK_COMB : code);
 }
 
 void launch_front(hipStream_t s, const GeomParams &gp, const ModelView &mv, const ClassTable &ct, int n_rays,
@@ -1335,7 +1397,7 @@ void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc)
 }
 
 void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, const float *vals, long plane,
-                 const float *elev, const signed char *mask, const double *weight_per_sub, int n_sub,
+                 const float *elev, signed char *mask, const double *weight_per_sub, int n_sub,
                  const double *phi_sc, int doppler, cpol_key_t *key, int *rank, float2 *lam, double *coef, double *n0d,
                  int *hist, double *vr)
 {
@@ -1343,7 +1405,7 @@ void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, cons
                        elev, mask, weight_per_sub, n_sub, phi_sc, doppler, key, rank, lam, coef, n0d, hist, vr);
 }
 
-// Offsets from the sharded bucket histogram (nb <= 16384 buckets x CPOL_SORT_SHARDS counters):
+// Offsets from the sharded bucket histogram (nb buckets x CPOL_SORT_SHARDS counters):
 // k_scan_shards (one thread per bucket) turns a bucket's counters into shard cursors relative to the
 // bucket start and leaves the bucket's unit and chunk counts in offs / chunk_off; k_scan_buckets (one
 // workgroup) scans those in place into bucket offsets and the chunk table of the integrate kernels.
@@ -1370,14 +1432,11 @@ __global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__
 {
     __shared__ int s_a[1024], s_b[1024];
     const int t = threadIdx.x;
-    const int per = (nb + 1023) / 1024;          // <= 16
-    int va[16], vb[16];
+    const int per = (nb + 1023) / 1024;          // a run of consecutive buckets per thread
     int a = 0, c = 0;
     for (int i = 0; i < per; i++) {
         int j = t * per + i;
-        va[i] = j < nb ? offs[j] : 0;
-        vb[i] = j < nb ? chunk_off[j] : 0;
-        a += va[i]; c += vb[i];
+        if (j < nb) { a += offs[j]; c += chunk_off[j]; }
     }
     s_a[t] = a; s_b[t] = c;
     __syncthreads();
@@ -1388,10 +1447,13 @@ __global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__
         __syncthreads();
     }
     int ea = s_a[t] - a, eb = s_b[t] - c;
-    for (int i = 0; i < per; i++) {
+    for (int i = 0; i < per; i++) {              // the thread's own run, in place: count -> offset
         int j = t * per + i;
-        if (j < nb) { offs[j] = ea; chunk_off[j] = eb; }
-        ea += va[i]; eb += vb[i];
+        if (j < nb) {
+            const int va = offs[j], vb = chunk_off[j];
+            offs[j] = ea; chunk_off[j] = eb;
+            ea += va; eb += vb;
+        }
     }
     if (t == 1023) { offs[nb] = s_a[1023]; chunk_off[nb] = s_b[1023]; }
 }
@@ -1455,21 +1517,24 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Table image (global and LDS alike, built by k_build_image):
 //   img[((q*4*NC + k*NC + j) * 4 + s] = B'[d][j]   with d = 16 q + 4 s + k
-// i.e. for the quad q of four consecutive MFMA steps s = 0..3, the lane (k = lane >> 4,
-// j = lane & 15 < NC) finds its four B operands in one 16-byte word.  NC = 12 (three
-// workgroups per CU) or 14 with the two Doppler scheme-2 moments (two per CU).
-template <int NC>
-__global__ __launch_bounds__(INTEG_THREADS, (NC == 12 ? 3 : 2) * (INTEG_THREADS / 256))
-void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
-                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, float4 *urec, const float2 *__restrict__ lam,
-                 float *__restrict__ psd_out, unsigned long long *__restrict__ work)
-{   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
+// i.e. for the quad q of four consecutive steps s = 0..3, a lane with diameter residue k finds the four B
+// operands of column j in one 16-byte word.  NC = 12 (the scattering components), 14 with the two Doppler
+// scheme-2 moments, or 8 for the combined columns (where the words of a row with k >= 2 are stored with the
+// two column groups exchanged, so that the 16 distinct words of a read fall into 16 different bank quarters).
+//
+// One chunk of <= CPOL_CHUNK_UNITS units of one bucket, integrated over an image of NC columns.  ROW floats per
+// result row in psd_out; with ROW = 8 columns 8..11 of a twelve-column unit go to psd_hi (4 floats per unit).
+template <int NC, int ROW>
+__device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, const float gstep, const bool cut_ok, const float cut_e,
+                                                const int ie, const int it, const int start, int cnt, const int *__restrict__ sorted,
+                                                float4 *urec, const float2 *__restrict__ lam, float *__restrict__ psd_out,
+                                                float *__restrict__ psd_hi, unsigned long long *__restrict__ work)
+{
     constexpr int SLICE_FLOATS = 1024 * NC;      // one (e, t) node of the permuted table
     constexpr int LDS_ZERO = SLICE_FLOATS;       // 64 zero floats (all banks) for the lanes of the spare columns
     constexpr int LDS_X = SLICE_FLOATS + 64;
     constexpr int UPT = CPOL_CHUNK_UNITS / INTEG_THREADS;       // units per thread in the chunk-local sort
     static_assert(CPOL_CHUNK_UNITS == UPT * INTEG_THREADS, "whole units per thread");
-    __shared__ __attribute__((aligned(16))) float lds[SLICE_FLOATS + 64 + 1024];
     // chunk-local counting sort of the units by the number of quads (16 diameters) their N(D) survives
     // (its 65 counters borrow the start of the table area, which is filled only afterwards: with them in a
     // region of their own the workgroup would pass the LDS size at which three fit a CU)
@@ -1477,28 +1542,6 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     // next to each other in cutoff order: a pass then fetches its 32 units with coalesced loads, no permutation
     // lives in LDS.
     int *s_hist = (int *)lds;
-
-    // XCD-aware chunk order: the workgroups of one XCD (blockIdx % 8) take runs of INTEG_XCD_RUN consecutive
-    // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2; the runs go round the XCDs
-    // because a chunk's cost depends on its class and node (cutoffs), and a contiguous eighth of the chunk
-    // list per XCD would leave some XCDs with all the expensive ones.
-    const unsigned total = (unsigned)chunk_off[nb];
-    const unsigned xcd = blockIdx.x % 8, kx = blockIdx.x / 8;
-    const unsigned cid = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
-    if (cid >= total) return;
-
-    const int bkt = chunk_bucket[cid];              // bucket of this chunk (k_fill_chunks)
-    const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
-    int cnt = offs[bkt + 1] - start;
-    if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
-
-    const int it = bkt % ct.nt_max;
-    const int ie = (bkt / ct.nt_max) % ct.ne_max;
-    const int hk = bkt / (ct.nt_max * ct.ne_max);          // kind * n_cls + class
-    const LutView lv = hk < ct.n_cls ? ct.lut[hk] : ct.lut_dop[hk - ct.n_cls];
-    const float gstep = hk < ct.n_cls ? ct.pol_geo_step[hk] : 0.f;     // 4 x diameter step when N(D) is geometric
-    const bool cut_ok = hk < ct.n_cls && ct.cut_ok[hk];                // D^nu ascending: N(D) = 0 past a unit's cutoff
-    const float cut_e = hk < ct.n_cls ? ct.cut_e[hk] : 152.f;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
@@ -1599,7 +1642,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const float4 *X4 = (const float4 *)(lds + LDS_X) + dr;
     int boff[NG];
 #pragma unroll
-    for (int g = 0; g < NG; g++) boff[g] = dr * NC + 4 * g + r4;
+    for (int g = 0; g < NG; g++) boff[g] = dr * NC + ((NC == CPOL_N_COMB && (dr & 2)) ? (4 * g + r4) ^ 4 : 4 * g + r4);
     // columns past NC (NC = 14: the last two of the fourth group): a zero word, the same for every quad
     const bool spare = 4 * (NG - 1) + r4 >= NC;
     const int bstride_last = spare ? 0 : 4 * NC;
@@ -1612,7 +1655,7 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     // ...) so that every wave gets cheap and expensive ones
     constexpr int NW = INTEG_THREADS / 64;
     for (int r8 = 0; r8 * NW < npass; r8++) {
-        const int ps = r8 * NW + ((r8 & 1) ? NW - 1 - wave : wave);
+        const int ps = __builtin_amdgcn_readfirstlane(r8 * NW + ((r8 & 1) ? NW - 1 - wave : wave));
         if (ps >= npass) continue;
         const int u0 = ps * 32;
         const int ua = u0 + ug * 4 + r4, ub = ua + 16;        // the lane's unit in either set
@@ -1621,15 +1664,17 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         if (ua < cnt) ra = urec[start + ua];
         if (ub < cnt) rb = urec[start + ub];
         const int nqa = __float_as_int(ra.z), nqb = __float_as_int(rb.z);      // quads the lane's units take part in
-        const float nha = -ra.x, nla = -ra.y, nhb = -rb.x, nlb = -rb.y;
+        const float ha = ra.x, la = ra.y, hb = rb.x, lb = rb.y;
         // Units come in cutoff order, so the first set ends no later than the second begins: both sets run up to
         // the quad count of the first set's last unit, the second alone from there to that of its own last unit.
         // Past the count of a set's first unit a lane sets its N(D) to zero once its own unit's count is reached:
         // a unit's sums cover its own quads whatever units share its pass.
         const int n_a = min(cnt - u0, 16), n_b = max(0, min(cnt - u0 - 16, 16));
-        const int a_lo = __shfl(nqa, 0), a_hi = __shfl(nqa, ((n_a - 1) >> 2) * 16 + ((n_a - 1) & 3));
-        const int b_lo = n_b ? __shfl(nqb, 0) : 0;
-        const int b_hi = n_b ? __shfl(nqb, ((n_b - 1) >> 2) * 16 + ((n_b - 1) & 3)) : 0;
+        // (wave-uniform values, kept in scalar registers: the loops below are controlled by scalar instructions)
+        const int a_lo = __builtin_amdgcn_readfirstlane(nqa);
+        const int a_hi = __builtin_amdgcn_readlane(nqa, ((n_a - 1) >> 2) * 16 + ((n_a - 1) & 3));
+        const int b_lo = n_b ? __builtin_amdgcn_readfirstlane(nqb) : 0;
+        const int b_hi = n_b ? __builtin_amdgcn_readlane(nqb, ((n_b - 1) >> 2) * 16 + ((n_b - 1) & 3)) : 0;
         if (dr == 0) own += (unsigned)((ua < cnt ? nqa : 0) + (ub < cnt ? nqb : 0));      // the units' own quad counts
         f32x4 acca[NG], accb[NG];
 #pragma unroll
@@ -1646,9 +1691,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             const int a_hi4 = (a_hi + 3) & ~3, b_hi4 = (b_hi + 3) & ~3;
             wsum += (unsigned)a_hi4 * (unsigned)n_a + (unsigned)b_hi4 * (unsigned)n_b;
             // one seed group of one set: quads q0 .. q0 + 3
-            auto seed_group = [&](int q0, float nh, float nl, float R, float R2, float R4, bool live, f32x4 *acc) {
+            auto seed_group = [&](int q0, float h, float l, float R, float R2, float R4, bool live, f32x4 *acc) {
                 const float x0 = X4[q0 * 4].x;
-                float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(nh, x0, nl * x0));
+                float n0 = __builtin_amdgcn_exp2f(__builtin_fmaf(-h, x0, -l * x0));
                 n0 = live ? n0 : 0.f;          // a unit that has had its seed groups: zero seed, zero terms
                 float n1 = n0 * R, n2 = n0 * R2;
                 float n3 = n1 * R2;
@@ -1671,10 +1716,10 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 }
             };
             for (int q0 = 0; q0 < a_hi4; q0 += 4) {
-                seed_group(q0, nha, nla, Ra, R2a, R4a, q0 < nqa4, acca);
-                if (n_b) seed_group(q0, nhb, nlb, Rb, R2b, R4b, true, accb);
+                seed_group(q0, ha, la, Ra, R2a, R4a, q0 < nqa4, acca);
+                if (n_b) seed_group(q0, hb, lb, Rb, R2b, R4b, true, accb);
             }
-            for (int q0 = a_hi4; q0 < b_hi4; q0 += 4) seed_group(q0, nhb, nlb, Rb, R2b, R4b, q0 < nqb4, accb);
+            for (int q0 = a_hi4; q0 < b_hi4; q0 += 4) seed_group(q0, hb, lb, Rb, R2b, R4b, q0 < nqb4, accb);
         } else {
             wsum += (unsigned)a_hi * (unsigned)n_a + (unsigned)b_hi * (unsigned)n_b;
             // Exponent argument -(hi + lo) x: the hi part by one fused multiply-add per value, the lo part (2^-24 of
@@ -1690,19 +1735,20 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 float na[4], nb_[4];
                 {
                     float ta, tb, p0, p1, p2, p3, p4, p5, p6, p7;
-                    asm volatile("v_mul_f32 %0, %12, %16\n\t"
-                                 "v_mul_f32 %1, %13, %16\n\t"
-                                 "v_fma_f32 %2, %10, %14, %0\n\t"
-                                 "v_fma_f32 %3, %11, %14, %1\n\t"
-                                 "v_fma_f32 %4, %10, %15, %0\n\t"
-                                 "v_fma_f32 %5, %11, %15, %1\n\t"
-                                 "v_fma_f32 %6, %10, %16, %0\n\t"
-                                 "v_fma_f32 %7, %11, %16, %1\n\t"
-                                 "v_fma_f32 %8, %10, %17, %0\n\t"
-                                 "v_fma_f32 %9, %11, %17, %1"
+                    // (the slopes enter negated through the instructions' source modifiers)
+                    asm volatile("v_mul_f32 %0, -%12, %16\n\t"
+                                 "v_mul_f32 %1, -%13, %16\n\t"
+                                 "v_fma_f32 %2, -%10, %14, %0\n\t"
+                                 "v_fma_f32 %3, -%11, %14, %1\n\t"
+                                 "v_fma_f32 %4, -%10, %15, %0\n\t"
+                                 "v_fma_f32 %5, -%11, %15, %1\n\t"
+                                 "v_fma_f32 %6, -%10, %16, %0\n\t"
+                                 "v_fma_f32 %7, -%11, %16, %1\n\t"
+                                 "v_fma_f32 %8, -%10, %17, %0\n\t"
+                                 "v_fma_f32 %9, -%11, %17, %1"
                                  : "=&v"(ta), "=&v"(tb), "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "=&v"(p4), "=&v"(p5),
                                    "=&v"(p6), "=&v"(p7)
-                                 : "v"(nha), "v"(nhb), "v"(nla), "v"(nlb), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
+                                 : "v"(ha), "v"(hb), "v"(la), "v"(lb), "v"(xx[0]), "v"(xx[1]), "v"(xx[2]), "v"(xx[3]));
                     na[0] = __builtin_amdgcn_exp2f(p0); nb_[0] = __builtin_amdgcn_exp2f(p1);
                     na[1] = __builtin_amdgcn_exp2f(p2); nb_[1] = __builtin_amdgcn_exp2f(p3);
                     na[2] = __builtin_amdgcn_exp2f(p4); nb_[2] = __builtin_amdgcn_exp2f(p5);
@@ -1728,14 +1774,14 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            auto quad1 = [&](int qd, float nh, float nl, int nq_own, int lo, f32x4 *acc) {      // one set
+            auto quad1 = [&](int qd, float h, float l, int nq_own, int lo, f32x4 *acc) {      // one set
                 float4 bq[NG];
 #pragma unroll
                 for (int g = 0; g < NG; g++) bq[g] = B4[boff[g] + qd * (g == NG - 1 ? bstride_last : 4 * NC)];
                 const float4 xq = X4[qd * 4];
-                const float t = nl * xq.z;
-                float n[4] = {__builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.x, t)), __builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.y, t)),
-                              __builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.z, t)), __builtin_amdgcn_exp2f(__builtin_fmaf(nh, xq.w, t))};
+                const float t = -l * xq.z;
+                float n[4] = {__builtin_amdgcn_exp2f(__builtin_fmaf(-h, xq.x, t)), __builtin_amdgcn_exp2f(__builtin_fmaf(-h, xq.y, t)),
+                              __builtin_amdgcn_exp2f(__builtin_fmaf(-h, xq.z, t)), __builtin_amdgcn_exp2f(__builtin_fmaf(-h, xq.w, t))};
                 if (qd >= lo) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; s4++) n[s4] = qd < nq_own ? n[s4] : 0.f;
@@ -1752,9 +1798,9 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
             };
             if (n_b) {
                 for (int qd = 0; qd < a_hi; qd++) quad2(qd);
-                for (int qd = a_hi; qd < b_hi; qd++) quad1(qd, nhb, nlb, nqb, b_lo, accb);
+                for (int qd = a_hi; qd < b_hi; qd++) quad1(qd, hb, lb, nqb, b_lo, accb);
             } else {
-                for (int qd = 0; qd < a_hi; qd++) quad1(qd, nha, nla, nqa, a_lo, acca);
+                for (int qd = 0; qd < a_hi; qd++) quad1(qd, ha, la, nqa, a_lo, acca);
             }
         }
         // The four residues' partial sums meet (rotations by eight and by four lanes inside each row of 16 lanes, an
@@ -1763,11 +1809,11 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
         // 16 floats, each 16-byte piece written by four neighbouring lanes; with twelve columns the fourth piece is
         // zeros, so that every row is written whole.
         {
-            constexpr int ROW = CPOL_N_COL;
             auto finish = [&](int base, const f32x4 *acc) {
                 const int un = base + ug * 4 + dr;
                 if (base >= cnt) return;                 // wave-uniform: the set is empty
-                const long row = un < cnt ? (long)__float_as_int(urec[start + un].w) * ROW : 0;
+                const long uslot = un < cnt ? (long)__float_as_int(urec[start + un].w) : 0;
+                const long row = uslot * ROW;
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
                     float t[4];
@@ -1780,7 +1826,10 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
                         t[v] = x;
                     }
                     const float val = dr == 0 ? t[0] : dr == 1 ? t[1] : dr == 2 ? t[2] : t[3];
-                    if (un < cnt) psd_out[row + 4 * g + r4] = val;
+                    if (un < cnt) {
+                        if (4 * g < ROW) psd_out[row + 4 * g + r4] = val;
+                        else psd_hi[uslot * 4 + r4] = val;          // columns 8..11 beside rows of eight floats
+                    }
                 }
                 if (NG * 4 < ROW && un < cnt) {
 #pragma unroll
@@ -1801,18 +1850,62 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     }
 }
 
+// NCA: columns of the image that planes [0, n_cls) are integrated over; NCB: 0, or the columns of the image of the
+// planes [n_cls, 2 n_cls) when the configuration has two forms of polarimetric unit (ClassTable::comb: NCA = 8
+// combined columns, NCB = 12).  Three workgroups per CU up to 12 columns (48 KB slice), two with 14.
+template <int NCA, int NCB>
+__global__ __launch_bounds__(INTEG_THREADS, ((NCA > NCB ? NCA : NCB) <= 12 ? 3 : 2) * (INTEG_THREADS / 256))
+void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
+                 const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, float4 *urec, const float2 *__restrict__ lam,
+                 float *__restrict__ psd_out, float *__restrict__ psd_hi, unsigned long long *__restrict__ work)
+{   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
+    constexpr int NCMAX = NCA > NCB ? NCA : NCB;
+    constexpr int ROW = NCB ? CPOL_N_COMB : CPOL_N_COL;
+    __shared__ __attribute__((aligned(16))) float lds[1024 * NCMAX + 64 + 1024];
+
+    // XCD-aware chunk order: the workgroups of one XCD (blockIdx % 8) take runs of INTEG_XCD_RUN consecutive
+    // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2; the runs go round the XCDs
+    // because a chunk's cost depends on its class and node (cutoffs), and a contiguous eighth of the chunk
+    // list per XCD would leave some XCDs with all the expensive ones.
+    const unsigned total = (unsigned)chunk_off[nb];
+    const unsigned xcd = blockIdx.x % 8, kx = blockIdx.x / 8;
+    const unsigned cid = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
+    if (cid >= total) return;
+
+    const int bkt = chunk_bucket[cid];              // bucket of this chunk (k_fill_chunks)
+    const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
+    int cnt = offs[bkt + 1] - start;
+    if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
+
+    const int it = bkt % ct.nt_max;
+    const int ie = (bkt / ct.nt_max) % ct.ne_max;
+    const int plane = bkt / (ct.nt_max * ct.ne_max);       // form * n_cls + class
+    const int h = plane % ct.n_cls;
+    const float gstep = ct.pol_geo_step[h];                // 4 x diameter step when N(D) is geometric
+    const bool cut_ok = ct.cut_ok[h];                      // D^nu ascending: N(D) = 0 past a unit's cutoff
+    const float cut_e = ct.cut_e[h];
+    if (NCB && plane >= ct.n_cls)
+        integrate_chunk<NCB ? NCB : NCA, ROW>(lds, ct.lut[h], gstep, cut_ok, cut_e, ie, it, start, cnt, sorted, urec, lam, psd_out, psd_hi, work);
+    else
+        integrate_chunk<NCA, ROW>(lds, NCB ? ct.lut_comb[h] : ct.lut[h], gstep, cut_ok, cut_e, ie, it, start, cnt, sorted, urec, lam, psd_out, psd_hi, work);
+}
+
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, float4 *urec, const float2 *lam,
-                      float *psd_out, unsigned long long *work)
+                      float *psd_out, float *psd_hi, unsigned long long *work)
 {
     if (max_chunks <= 0) return;
     max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
-    if (ct.ncol == 12)
-        hipLaunchKernelGGL(k_integrate<12>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, urec, lam, psd_out, work);
+    const dim3 grid((unsigned)max_chunks), block(INTEG_THREADS);
+    if (ct.comb)
+        hipLaunchKernelGGL((k_integrate<CPOL_N_COMB, 12>), grid, block, 0, s, ct, nb, offs, chunk_off, chunk_bucket, sorted, urec, lam,
+                           psd_out, psd_hi, work);
+    else if (ct.ncol == 12)
+        hipLaunchKernelGGL((k_integrate<12, 0>), grid, block, 0, s, ct, nb, offs, chunk_off, chunk_bucket, sorted, urec, lam,
+                           psd_out, psd_hi, work);
     else
-        hipLaunchKernelGGL(k_integrate<14>, dim3((unsigned)max_chunks), dim3(INTEG_THREADS), 0, s, ct, nb, offs, chunk_off,
-                           chunk_bucket, sorted, urec, lam, psd_out, work);
+        hipLaunchKernelGGL((k_integrate<14, 0>), grid, block, 0, s, ct, nb, offs, chunk_off, chunk_bucket, sorted, urec, lam,
+                           psd_out, psd_hi, work);
 }
 
 // =============================================================================
@@ -1875,7 +1968,7 @@ void k_integrate_dop(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ 
     const int start = offs[bkt - b_lo] + rel0;
     const int it = bkt % ct.nt_max;
     const int ie = (bkt / ct.nt_max) % ct.ne_max;
-    const int h = bkt / (ct.nt_max * ct.ne_max) - ct.n_cls;
+    const int h = (bkt / (ct.nt_max * ct.ne_max) - ct.n_pol_planes) % ct.n_cls;       // twin planes follow the polarimetric ones, form by form
     const LutView lv = ct.lut_dop[h];
     const int tid = threadIdx.x;
     {
@@ -2112,7 +2205,7 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
 #define GR_OCC 7
 __global__ __launch_bounds__(GR_THREADS, GR_OCC)
 void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restrict__ key, const double *__restrict__ coef,
-                   const float *__restrict__ psd_out, const signed char *__restrict__ mask,
+                   const float *__restrict__ psd_out, const float *__restrict__ psd_hi, const signed char *__restrict__ mask,
                    const double *__restrict__ wsub, const double *__restrict__ vr, float *__restrict__ obs,
                    long obs_plane, long ray0, double *__restrict__ mask_out, double *__restrict__ rvel_out, Dop2In d2)
 {
@@ -2121,35 +2214,97 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     if (t >= (long)n_rays * G) return;
     const int r = (int)(t / G), g = (int)(t % G);
     const float qnan = __builtin_nanf("");
-    float tot[CPOL_N_SZ];
-#pragma unroll
-    for (int k = 0; k < CPOL_N_SZ; k++) tot[k] = 0.f;
-    double msum = 0, rv = __builtin_nan(""), sw = 0;
-    for (int h = 0; h < op.n_cls; h++) {
-        float acc[CPOL_N_SZ];
-#pragma unroll
-        for (int k = 0; k < CPOL_N_SZ; k++) acc[k] = qnan;
-        for (int b = 0; b < B; b++) {
-            long u = ((long)r * B + b) * G + g;
-            long slot = (long)h * nu + u;
-            if (key[slot] < 0) continue;
-            double c = coef[slot];
-            const float4 *p = (const float4 *)(psd_out + slot * op.row);
-            float4 v0 = p[0], v1 = p[1], v2 = p[2];
-            const float vv[CPOL_N_SZ] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-            for (int k = 0; k < CPOL_N_SZ; k++) {
-                double v = (double)vv[k] * c;
-                double sm = (acc[k] != acc[k] ? 0. : (double)acc[k]) + (v != v ? 0. : v);
-                acc[k] = (float)sm;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < CPOL_N_SZ; k++) tot[k] += (acc[k] != acc[k]) ? 0.f : acc[k];
+    // the twelve sums of one unit: a row of 16 floats, or (combined columns in use) eight floats and four beside them
+    auto twelve = [&](long slot, float *vv) {
+        const float4 *p = (const float4 *)(psd_out + slot * op.row);
+        const float4 v0 = p[0], v1 = p[1], v2 = op.comb ? *(const float4 *)(psd_hi + slot * 4) : p[2];
+        vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
+        vv[8] = v2.x; vv[9] = v2.y; vv[10] = v2.z; vv[11] = v2.w;
+    };
+    // The quantities the observables are made of (scattering_sz.py:168-194):
+    //   bq = s0 - s1 - s2 + s3, cq = s0 + s1 + s2 + s3, a1 = s4 + s7, a2 = s6 - s5, kd = s10 - s8, s11, s9
+    float bq, cq, a1, a2, kd, s11, s9;
+    // Does the gate hold a unit in the combined form (the PSD set-up marks its point with CPOL_MASK_COMB)?  The twelve
+    // components of such a gate are never formed: the unit adds to each of them an amount of the size of a normal
+    // float32 (ClassTable::comb), so scattering_sz.py:110 finds no exact zero to turn into NaN unless contributions
+    // cancel exactly, and the gate's combinations are the sums of its units'.
+    bool comb_gate = false;
+    double msum = 0;
+    for (int b = 0; b < B; b++) {
+        const int m = mask[((long)r * B + b) * G + g];
+        comb_gate = comb_gate || m == CPOL_MASK_COMB;
+        msum += m == CPOL_MASK_COMB ? 0. : (double)m;
     }
+    if (comb_gate) {
+        double C[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) C[k] = 0.;
+        for (int h = 0; h < op.n_cls; h++)
+            for (int b = 0; b < B; b++) {
+                const long slot = (long)h * nu + ((long)r * B + b) * G + g;
+                const int kk = key[slot];
+                if (kk < 0) continue;
+                const double c = coef[slot];
+                double gq[7];
+                if (kk < op.nb_form) {
+                    const float4 *p = (const float4 *)(psd_out + slot * CPOL_N_COMB);
+                    const float4 v0 = p[0], v1 = p[1];
+                    gq[0] = v0.x; gq[1] = v0.y; gq[2] = v0.z; gq[3] = v0.w; gq[4] = v1.x; gq[5] = v1.y; gq[6] = v1.z;
+                } else {
+                    float vv[CPOL_N_SZ];
+                    twelve(slot, vv);
+                    const double z0 = vv[0], z1 = vv[1], z2 = vv[2], z3 = vv[3];
+                    gq[0] = ((z0 - z1) - z2) + z3; gq[1] = ((z0 + z1) + z2) + z3;
+                    gq[2] = (double)vv[4] + (double)vv[7]; gq[3] = (double)vv[6] - (double)vv[5];
+                    gq[4] = (double)vv[10] - (double)vv[8]; gq[5] = vv[11]; gq[6] = vv[9];
+                }
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    const double v = gq[k] * c;
+                    C[k] += (v != v ? 0. : v);           // nansum_arr: a NaN counts as zero (utilities.py:46-66)
+                }
+            }
+        bq = (float)C[0]; cq = (float)C[1]; a1 = (float)C[2]; a2 = (float)C[3]; kd = (float)C[4]; s11 = (float)C[5]; s9 = (float)C[6];
+    } else {
+        // every component as the reference accumulates it: float32 storage after every sub-beam (scattering_sz.py:38,
+        // 105), float32 class sum (:109), exact zeros to NaN (:110)
+        float tot[CPOL_N_SZ];
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) tot[k] = 0.f;
+        for (int h = 0; h < op.n_cls; h++) {
+            float acc[CPOL_N_SZ];
+#pragma unroll
+            for (int k = 0; k < CPOL_N_SZ; k++) acc[k] = qnan;
+            for (int b = 0; b < B; b++) {
+                long u = ((long)r * B + b) * G + g;
+                long slot = (long)h * nu + u;
+                if (key[slot] < 0) continue;
+                double c = coef[slot];
+                float vv[CPOL_N_SZ];
+                twelve(slot, vv);
+#pragma unroll
+                for (int k = 0; k < CPOL_N_SZ; k++) {
+                    double v = (double)vv[k] * c;
+                    double sm = (acc[k] != acc[k] ? 0. : (double)acc[k]) + (v != v ? 0. : v);
+                    acc[k] = (float)sm;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CPOL_N_SZ; k++) tot[k] += (acc[k] != acc[k]) ? 0.f : acc[k];
+        }
+        float s[CPOL_N_SZ];
+#pragma unroll
+        for (int k = 0; k < CPOL_N_SZ; k++) s[k] = (tot[k] == 0.f) ? qnan : tot[k];
+        // float32 in the reference's order
+        bq = ((s[0] - s[1]) - s[2]) + s[3];
+        cq = ((s[0] + s[1]) + s[2]) + s[3];
+        a1 = s[4] + s[7]; a2 = s[6] - s[5];
+        kd = s[10] - s[8];
+        s11 = s[11]; s9 = s[9];
+    }
+    double rv = __builtin_nan(""), sw = 0;
     for (int b = 0; b < B; b++) {
         long u = ((long)r * B + b) * G + g;
-        msum += (double)mask[u];
         if (op.doppler == 1 || op.doppler == 2) {
             double pw = op.doppler == 2 ? doppler2_radial(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
             double w = wsub[b];
@@ -2158,25 +2313,19 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
             rv = (rv != rv ? 0. : rv) + (tt != tt ? 0. : tt);
         }
     }
-    float s[CPOL_N_SZ];
-#pragma unroll
-    for (int k = 0; k < CPOL_N_SZ; k++) s[k] = (tot[k] == 0.f) ? qnan : tot[k];
-    // get_pol_from_sz, float32 in the reference's order
-    float bq = ((s[0] - s[1]) - s[2]) + s[3];
-    float cq = ((s[0] + s[1]) + s[2]) + s[3];
+    // get_pol_from_sz, float32
     float xs_h = op.two_pi * bq, xs_v = op.two_pi * cq;
-    float a1 = s[4] + s[7], a2 = s[6] - s[5];
     float aq = a1 * a1 + a2 * a2;
-    float delta = atan2f(s[5] - s[6], (-s[4]) - s[7]);
+    float delta = atan2f(-a2, -a1);             // arctan2(s5 - s6, -s4 - s7): both arguments are exact negations
     const long o = (ray0 + r) * (long)G + g;
     obs[CPOL_O_ZH * obs_plane + o] = op.zfac * xs_h;
     obs[CPOL_O_ZV * obs_plane + o] = op.zfac * xs_v;
     obs[CPOL_O_ZDR * obs_plane + o] = xs_h / xs_v;
-    obs[CPOL_O_KDP * obs_plane + o] = op.kdpfac * (s[10] - s[8]) + delta;        // KDP + delta_hv (scattering_sz.py:117)
+    obs[CPOL_O_KDP * obs_plane + o] = op.kdpfac * kd + delta;        // KDP + delta_hv (scattering_sz.py:117)
     obs[CPOL_O_DELTA_HV * obs_plane + o] = delta;
     obs[CPOL_O_RHOHV * obs_plane + o] = sqrtf(aq / (bq * cq));
-    obs[CPOL_O_AH * obs_plane + o] = op.afac * (op.two_wl * s[11]);
-    obs[CPOL_O_AV * obs_plane + o] = op.afac * (op.two_wl * s[9]);
+    obs[CPOL_O_AH * obs_plane + o] = op.afac * (op.two_wl * s11);
+    obs[CPOL_O_AV * obs_plane + o] = op.afac * (op.two_wl * s9);
     if (mask_out) {
         double m = msum / (double)B;
         if (m >= 0 && m < 1) m = 0;
@@ -2273,13 +2422,13 @@ void k_ray_scan(ObsParams op, float *__restrict__ obs, long obs_plane, long ray0
 }
 
 void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu, const cpol_key_t *key,
-                        const double *coef, const float *psd_out, const signed char *mask,
+                        const double *coef, const float *psd_out, const float *psd_hi, const signed char *mask,
                         const double *weight_per_sub, const double *vr, float *obs, long obs_plane,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel)
 {
     const long n = (long)n_rays * op.n_gates;
     hipLaunchKernelGGL(k_gate_reduce, dim3((unsigned)((n + GR_THREADS - 1) / GR_THREADS)), dim3(GR_THREADS), 0, s, op, n_rays, nu, key, coef,
-                       psd_out, mask, weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
+                       psd_out, psd_hi, mask, weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
     hipLaunchKernelGGL(k_ray_scan, dim3(n_rays), dim3(64), 0, s, op, obs, obs_plane, ray0, rvel_out, spectrum,
                        n_vel);
 }
@@ -2426,7 +2575,7 @@ void k_spectrum(ClassTable ct, SpecParams sp, long /*n_positions*/, const float 
         const long rb = (long)r * B + b;
         const long u = rb * G + g;
         SpecSub ss;
-        ss.active = mask[u] == 0;                         // doppler_sz.py:271
+        ss.active = mask[u] == 0 || mask[u] == CPOL_MASK_COMB;      // doppler_sz.py:271 (both codes: the point lies inside the model)
         const float T = vals[(long)CPOL_V_T * plane + u];
         const float e_raw = elev[u];
         const float e_lut = fold_elev(e_raw);

@@ -130,6 +130,9 @@ int cpol_timing_read(cpol_ctx *ctx, double stage_ms[CPOL_N_STAGES], long stage_l
  * run on to the stopping point of the last unit of its group of 32. */
 int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *doppler_unit_diameters,
                      double *own_unit_diameters);
+/* How many of the valid units counted by cpol_timing_read were integrated over the combined columns (see
+ * cpol_set_column_combination) while timing was enabled.  No counterpart in the reference. */
+int cpol_timing_forms(cpol_ctx *ctx, double *combined_units);
 /* Which terms of the PSD integration (scattering_sz.py:95-103: all 1024 diameters, float64) are evaluated.  The
  * terms whose N(D) = exp(-lambda D^nu) underflows to an exact float32 zero are always left out.  With
  * certified != 0 (the default) a class may stop earlier, at N(D) < 2^-E N(D_0), E in {48 .. 128}: when its tables
@@ -143,6 +146,27 @@ int cpol_timing_work(cpol_ctx *ctx, double *evaluated_unit_diameters, double *do
  * spectrum is bit for bit the one of certified = 0.  No counterpart in the reference. */
 int cpol_set_term_cutoff(cpol_ctx *ctx, int certified);
 int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES]);
+/* Over which columns the PSD integration runs.  The observables are functions of seven linear combinations of the
+ * twelve scattering components (get_pol_from_sz, scattering_sz.py:168-194: s0 - s1 - s2 + s3, s0 + s1 + s2 + s3,
+ * s4 + s7, s6 - s5, s10 - s8, s11, s9), and integration is linear, so a unit (gate x sub-beam x class) may be
+ * integrated over those seven columns of the table instead of all twelve.  What the reference does with the twelve
+ * sums that this would lose is the rule of scattering_sz.py:110 - a component whose sum over sub-beams and classes is
+ * an exact zero becomes NaN - and the float32 storage of each component after every sub-beam (:38,105) where that
+ * storage underflows.  With on != 0 (the default) a unit therefore takes the combined columns only when neither can
+ * touch it: every column of its table node has one sign along the whole diameter axis, so that the first diameter's
+ * term bounds the magnitude of each of its twelve sums from below, and the unit's coefficient times the smallest such
+ * term of the node is at least 2^-100 - its contribution to every component is then a normal float32 far from the
+ * subnormals.  Every other unit is integrated over all twelve columns, and a gate that holds no unit of the first
+ * kind is reduced exactly as the reference reduces it.  A gate that holds one is reduced from the combinations,
+ * accumulated in float64: none of its components can be an exact zero unless nonzero contributions cancel exactly,
+ * which needs unrelated floats to be exact negatives of each other and is the one case not reproduced; its
+ * observables differ from the reference's float32 accumulation of the components by that accumulation's own rounding
+ * (a few 1e-7 of a component).  on = 0: all units over all twelve columns.  The setting does not apply when the two
+ * Doppler scheme-2 moments ride on the polarimetric units (1-moment input), which then take all columns.
+ * cpol_get_column_combination reports per class how many table nodes qualify (all 0: no unit takes the combined
+ * columns).  No counterpart in the reference. */
+int cpol_set_column_combination(cpol_ctx *ctx, int on);
+int cpol_get_column_combination(cpol_ctx *ctx, long nodes_per_class[CPOL_MAX_CLASSES]);
 
 /* 1 when the uploaded model lets the vertical interpolation (interpolation_c.c:151, four float32 divisions per
  * point, column and variable) share one refined reciprocal per level pair - the same bits as the division as long
