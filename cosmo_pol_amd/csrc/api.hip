@@ -242,7 +242,7 @@ static int fail(cpol_ctx *ctx, int code, const char *msg)
 // on, held until the process ends.  `scratch` is a host-side stand-in for the symbol, not a device address: the
 // address on each device comes from hipGetSymbolAddress (once per device, in cpol_create) and only that pointer
 // is ever handed to kernels, memsets or copies.
-#define CPOL_STATIC_SCRATCH_BYTES ((size_t)64 << 20)
+#define CPOL_STATIC_SCRATCH_BYTES ((size_t)80 << 20)
 static __device__ __align__(256) unsigned char scratch[CPOL_STATIC_SCRATCH_BYTES];
 #define CPOL_MAX_DEVICES 64
 static void *g_scratch_ptr[CPOL_MAX_DEVICES];      // device address of `scratch` on each device, nullptr = not asked yet
@@ -655,11 +655,13 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
     // two forms of polarimetric unit when any node qualifies for the combined columns
     bool any = false;
     for (int h = 0; h < ct.n_cls; h++) any = any || (want_comb && ctx->lut[h].table_comb && ctx->lut[h].nodes_comb > 0);
+    // at most 32768 buckets (unit kind x form x class x elevation node x temperature node): their sort counters are
+    // part of the workspace (17 MB at the limit), and a polarimetric bucket's number must fit cpol_key_t
     const long pol_nodes = (long)ct.n_cls * ct.ne_max * ct.nt_max;
-    ct.comb = (any && 2 * pol_nodes <= 32767) ? 1 : 0;
+    if ((long)ct.n_kinds * pol_nodes > 32768)
+        return fail(ctx, CPOL_ERR_ARG, "more than 32768 lookup-table nodes (unit kind x class x elevation x temperature)");
+    ct.comb = (any && (long)ct.n_kinds * 2 * pol_nodes <= 32768) ? 1 : 0;
     ct.n_pol_planes = ct.n_cls * (1 + ct.comb);
-    if (pol_nodes * (1 + ct.comb) > 32767)
-        return fail(ctx, CPOL_ERR_ARG, "more than 32767 lookup-table nodes (class x elevation x temperature)");
     return CPOL_OK;
 }
 
@@ -712,7 +714,8 @@ static int ensure_physics(cpol_ctx *ctx, const ClassTable &ct, long nu)
     if (ct.comb) TRY(ensure(ctx, ctx->w->b_psd_hi, (size_t)nu * ct.n_cls * 4 * sizeof(float)));
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->w->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_cbkt, (size_t)((nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb + 1) * sizeof(int)));
-    TRY(ensure(ctx, ctx->w->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1)) * sizeof(int)));
+    // counters, shard cursors, bucket offsets, chunk offsets, and the run totals of the two-level scan (launch_scan)
+    TRY(ensure(ctx, ctx->w->b_hist, (size_t)((2 * CPOL_SORT_SHARDS + 2) * (nb + 1) + 2 * CPOL_SCAN_RUNS_MAX) * sizeof(int)));
     if (ctx->cfg.doppler_scheme) TRY(ensure(ctx, ctx->w->b_vr, nu * sizeof(double)));
     if (ctx->cfg.doppler_scheme == 2) TRY(ensure(ctx, ctx->w->b_n0d, nslots * sizeof(double)));
     return CPOL_OK;

@@ -9,6 +9,7 @@
 #define CPOL_WAVE 64
 #define CPOL_CHUNK_UNITS 1024      // units (gate x sub-beam x class) per integrate workgroup
 typedef short cpol_key_t;         // bucket (class, elevation node, temperature node) of a unit, -1 = not valid; at most 16384 buckets
+#define CPOL_SCAN_RUNS_MAX 1024    // runs of 256 buckets in the two-level bucket scan: at most 262144 buckets
 #define CPOL_SORT_SHARDS 64         // counters per bucket: spreads same-address atomics of big buckets
 #define CPOL_DOP_SLICE 3072       // floats per node of the compact Doppler image: 256 x 3 words of 4
 #define CPOL_LINE_N 40            // doubles per (ray, sub-beam) record of the geodesic line constants

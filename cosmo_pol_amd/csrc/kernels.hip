@@ -1406,38 +1406,53 @@ void launch_prep(hipStream_t s, const ClassTable &ct, long nu, int n_gates, cons
 }
 
 // Offsets from the sharded bucket histogram (nb buckets x CPOL_SORT_SHARDS counters):
-// k_scan_shards (one thread per bucket) turns a bucket's counters into shard cursors relative to the
-// bucket start and leaves the bucket's unit and chunk counts in offs / chunk_off; k_scan_buckets (one
-// workgroup) scans those in place into bucket offsets and the chunk table of the integrate kernels.
-__global__ void k_scan_shards(int nb, int nb_counted, const int *__restrict__ hist, int *__restrict__ offs,
-                              int *__restrict__ cursor, int *__restrict__ chunk_off)
+// k_scan_shards (one thread per bucket, workgroups of SCAN_BLOCK buckets) turns a bucket's counters into shard
+// cursors relative to the bucket start, and leaves in offs / chunk_off the bucket's unit and chunk offsets inside its
+// workgroup's run of buckets and in blk_tot the run's totals; k_scan_buckets (one workgroup) scans the totals and adds
+// every run's base to its buckets: bucket offsets and the chunk table of the integrate kernels.
+#define SCAN_BLOCK 256
+__global__ __launch_bounds__(SCAN_BLOCK)
+void k_scan_shards(int nb, int nb_counted, const int *__restrict__ hist, int *__restrict__ offs,
+                   int *__restrict__ cursor, int *__restrict__ chunk_off, int *__restrict__ blk_tot)
 {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nb) return;
-    // buckets beyond nb_counted (separate Doppler units) mirror the counters of bucket j - nb_counted
-    const int4 *h4 = (const int4 *)(hist + (j < nb_counted ? j : j - nb_counted) * CPOL_SORT_SHARDS);
-    int4 *c4 = (int4 *)(cursor + j * CPOL_SORT_SHARDS);
+    __shared__ int s_v[SCAN_BLOCK / 64], s_c[SCAN_BLOCK / 64];
+    const int j = blockIdx.x * SCAN_BLOCK + threadIdx.x;
     int v = 0;
+    if (j < nb) {
+        // buckets beyond nb_counted (separate Doppler units) mirror the counters of bucket j - nb_counted
+        const int4 *h4 = (const int4 *)(hist + (j < nb_counted ? j : j - nb_counted) * CPOL_SORT_SHARDS);
+        int4 *c4 = (int4 *)(cursor + j * CPOL_SORT_SHARDS);
 #pragma unroll
-    for (int i = 0; i < CPOL_SORT_SHARDS / 4; i++) {
-        int4 h = h4[i], c;
-        c.x = v; v += h.x; c.y = v; v += h.y; c.z = v; v += h.z; c.w = v; v += h.w;
-        c4[i] = c;
+        for (int i = 0; i < CPOL_SORT_SHARDS / 4; i++) {
+            int4 h = h4[i], c;
+            c.x = v; v += h.x; c.y = v; v += h.y; c.z = v; v += h.z; c.w = v; v += h.w;
+            c4[i] = c;
+        }
     }
-    offs[j] = v;
-    chunk_off[j] = (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
+    const int c = (v + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS;
+    // exclusive scan of (v, c) over the workgroup's buckets
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int iv = v, ic = c;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int ov = __shfl_up(iv, m), oc = __shfl_up(ic, m);
+        if (lane >= m) { iv += ov; ic += oc; }
+    }
+    if (lane == 63) { s_v[wv] = iv; s_c[wv] = ic; }
+    __syncthreads();
+    int bv = 0, bc = 0;
+    for (int w = 0; w < wv; w++) { bv += s_v[w]; bc += s_c[w]; }
+    if (j < nb) { offs[j] = bv + iv - v; chunk_off[j] = bc + ic - c; }
+    if (threadIdx.x == SCAN_BLOCK - 1) { blk_tot[2 * blockIdx.x] = bv + iv; blk_tot[2 * blockIdx.x + 1] = bc + ic; }
 }
 
-__global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__ chunk_off)
+__global__ __launch_bounds__(1024)
+void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__ chunk_off, const int *__restrict__ blk_tot)
 {
     __shared__ int s_a[1024], s_b[1024];
     const int t = threadIdx.x;
-    const int per = (nb + 1023) / 1024;          // a run of consecutive buckets per thread
-    int a = 0, c = 0;
-    for (int i = 0; i < per; i++) {
-        int j = t * per + i;
-        if (j < nb) { a += offs[j]; c += chunk_off[j]; }
-    }
+    const int nblk = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;          // <= 1024 runs
+    const int a = t < nblk ? blk_tot[2 * t] : 0, c = t < nblk ? blk_tot[2 * t + 1] : 0;
     s_a[t] = a; s_b[t] = c;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -1446,16 +1461,12 @@ __global__ void k_scan_buckets(int nb, int *__restrict__ offs, int *__restrict__
         s_a[t] += xa; s_b[t] += xb;
         __syncthreads();
     }
-    int ea = s_a[t] - a, eb = s_b[t] - c;
-    for (int i = 0; i < per; i++) {              // the thread's own run, in place: count -> offset
-        int j = t * per + i;
-        if (j < nb) {
-            const int va = offs[j], vb = chunk_off[j];
-            offs[j] = ea; chunk_off[j] = eb;
-            ea += va; eb += vb;
-        }
-    }
-    if (t == 1023) { offs[nb] = s_a[1023]; chunk_off[nb] = s_b[1023]; }
+    const int tot_a = s_a[1023], tot_b = s_b[1023];
+    __syncthreads();
+    s_a[t] -= a; s_b[t] -= c;                    // exclusive: the base of run t
+    __syncthreads();
+    for (int j = t; j < nb; j += 1024) { offs[j] += s_a[j / SCAN_BLOCK]; chunk_off[j] += s_b[j / SCAN_BLOCK]; }
+    if (t == 0) { offs[nb] = tot_a; chunk_off[nb] = tot_b; }
 }
 
 // Bucket of every chunk, so that an integrate workgroup finds its bucket with one load instead of a
@@ -1469,8 +1480,10 @@ __global__ void k_fill_chunks(const int *__restrict__ chunk_off, int *__restrict
 void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
                  int *chunk_bucket)
 {
-    hipLaunchKernelGGL(k_scan_shards, dim3((nb + 255) / 256), dim3(256), 0, s, nb, nb_counted, hist, offs, cursor, chunk_off);
-    hipLaunchKernelGGL(k_scan_buckets, dim3(1), dim3(1024), 0, s, nb, offs, chunk_off);
+    int *blk_tot = chunk_off + nb + 1;            // 2 x CPOL_SCAN_RUNS_MAX ints behind the chunk offsets
+    hipLaunchKernelGGL(k_scan_shards, dim3((nb + SCAN_BLOCK - 1) / SCAN_BLOCK), dim3(SCAN_BLOCK), 0, s, nb, nb_counted, hist, offs, cursor,
+                       chunk_off, blk_tot);
+    hipLaunchKernelGGL(k_scan_buckets, dim3(1), dim3(1024), 0, s, nb, offs, chunk_off, blk_tot);
     hipLaunchKernelGGL(k_fill_chunks, dim3(nb), dim3(64), 0, s, chunk_off, chunk_bucket);
 }
 

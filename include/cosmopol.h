@@ -286,12 +286,13 @@ int cpol_wait_async(cpol_ctx *ctx, int calls_back);
 /* The same hot path for callers that cannot allocate: code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same computation and same outputs as
  * cpol_run_rays_dev, bit for bit, but the call allocates nothing: every workspace is a piece of one array of
- * 64 MiB that the library keeps in the device memory of each GPU it runs on until the process ends.  For that:
+ * 80 MiB that the library keeps in the device memory of each GPU it runs on until the process ends.  For that:
  *   - n_rays x sub-beams x n_gates must not exceed CPOL_STATIC_MAX_POSITIONS (CPOL_ERR_ARG otherwise).  That is the
  *     only size limit: a position takes at most 725 bytes of the array (2-moment input with Doppler scheme 2), 47.5 MB
- *     at the limit; the sort counters take 520 bytes per lookup-table node and unit kind, and the library accepts at
- *     most 16384 such nodes (8.5 MB; 7.5 MB for the reference's 46 x 39-node tables of four classes with Doppler
- *     units of their own), so the two together stay below the 64 MiB whatever the tables;
+ *     at the limit, and outputs served from the array at most 76 bytes per gate; the sort counters take 520 bytes per
+ *     bucket (lookup-table node x unit kind x unit form), and the library accepts at most 32768 buckets (17 MB; 15 MB
+ *     for the reference's 46 x 39-node tables of four classes with Doppler units of their own and two forms of
+ *     polarimetric unit), so everything together stays below the 80 MiB whatever the tables;
  *   - azimuth_dev / elevation_dev are DEVICE arrays [n_rays] and are read in place;
  *   - cpol_set_config, cpol_upload_lut, cpol_upload_model and cpol_set_quadrature (which allocate and build the
  *     table images) must have been called before; doppler_scheme 3 is not served (CPOL_ERR_ARG);
