@@ -240,6 +240,105 @@ def test_certified_term_cutoff():
         assert np.abs(a[ok] / b[ok] - 1).max() <= 1e-5, n
 
 
+@pytest.mark.parametrize('scheme,dscheme,decades', [(2, 2, (-40, -24)), (1, 0, (-12, -8))])
+def test_combined_columns_against_all_twelve(scheme, dscheme, decades):
+    """Units whose contributions to all twelve components are of normal float32 size are integrated over the seven
+    combinations of columns the observables are made of, the others over all twelve columns
+    (cpol_set_column_combination).  Contents over 10 decades, and a stretch of gates scaled down much further: with
+    2-moment input until the components are subnormal float32 numbers, with 1-moment input (where the slope grows as the
+    content falls) until they underflow one after the other and the reference's rule 'an exact zero becomes NaN'
+    (scattering_sz.py:110) bites component by component.  The run with the combined columns and the run that takes
+    all twelve columns for every unit have the same NaN pattern, agree to float32 rounding where nothing cancels, and
+    both meet the oracle."""
+    conf = O.make_config(microphysics={'scheme': scheme}, attenuation={'correction': 0}, doppler={'scheme': dscheme},
+                         radar={'radial_resolution': 500., 'frequency': 5.6})
+    eng = make_engine(conf)
+    nodes = eng.ctx.get_column_combination()
+    assert sorted(nodes) == sorted(syn.hydrom_types(scheme)) and all(n > 0 for n in nodes.values()), nodes
+    beams = syn.synthetic_beams(300, 9, scheme, seed=777, res=500., zero_frac=0.1)
+    rng = np.random.default_rng(11)
+    tiny = slice(40, 110)
+    for b in beams:
+        for k, v in b['values'].items():
+            if k.startswith('Q') and k.endswith('_v'):
+                v *= (10. ** rng.uniform(-8, 2, v.shape)).astype(np.float32)
+                v[tiny] *= (10. ** rng.uniform(decades[0], decades[1], v[tiny].shape)).astype(np.float32)
+    obs1, mask1, rvel1 = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    eng.ctx.set_column_combination(False)
+    assert eng.ctx.get_column_combination() == {}
+    obs0, mask0, rvel0 = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    eng.ctx.set_column_combination(True)
+    assert eng.ctx.get_column_combination() == nodes
+    np.testing.assert_array_equal(mask1, mask0)
+    if dscheme:
+        np.testing.assert_array_equal(rvel1, rvel0)            # the Doppler units do not depend on the form
+    with np.errstate(all='ignore'):
+        want = O.get_radar_observables(util.oracle_beams(beams), util.oracle_luts(scheme, 5.6), conf)
+    n_nan = {}
+    # components that have left float32's normal range have few bits: values are compared where the reflectivity
+    # (and with it the cross terms, four decades below) and the attenuation are well inside it
+    with np.errstate(invalid='ignore'):
+        normal = (np.abs(np.asarray(want.values['ZH'])) > 1e-26) & (np.abs(np.asarray(want.values['AH'])) > 1e-30)
+    for i, n in enumerate(OBS):
+        a, b, w = obs1[i].astype(np.float64), obs0[i].astype(np.float64), np.asarray(want.values[n], dtype=np.float64)
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b), err_msg=n)
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(w), err_msg=n)
+        n_nan[n] = int(np.isnan(w[tiny]).sum())
+        ok = ~np.isnan(w) & normal
+        if n == 'RHOHV':               # made of float32 squares of components (scattering_sz.py:188), which are subnormal
+            with np.errstate(invalid='ignore'):          # below 1e-19: a reflectivity of 1e-15 and less
+                ok &= np.abs(np.asarray(want.values['ZH'])) > 1e-12
+        if n in ('ZH', 'ZV', 'ZDR', 'AH', 'AV', 'RHOHV'):
+            assert np.abs(a[ok] / b[ok] - 1).max() <= 1e-6, n
+            assert np.abs(a[ok] / w[ok] - 1).max() <= 1e-5, n
+            assert np.abs(b[ok] / w[ok] - 1).max() <= 1e-5, n
+    # the regime is in the test: tiny but present components everywhere (2-moment), components lost one by one (1-moment)
+    if scheme == 2:
+        assert np.nanmax(np.abs(np.asarray(want.values['AH'])[tiny])) < 1e-29 and n_nan['AH'] == 0, n_nan
+    else:
+        assert 10 < n_nan['AH'] < n_nan['ZH'] < n_nan['RHOHV'] < 70, n_nan
+    # the whole bar on the gates of ordinary contents
+    keep = np.r_[0:40, 110:300]
+    check_obs(obs1[:, keep], {n: np.asarray(v)[keep] for n, v in want.values.items()}, 'combined', 500., exact_scan=False)
+    check_obs(obs0[:, keep], {n: np.asarray(v)[keep] for n, v in want.values.items()}, 'all twelve', 500., exact_scan=False)
+
+
+def test_combined_columns_and_a_table_with_a_zero_column():
+    """Hail whose cross terms s1, s2 are exact zeros (spheres): a gate that holds nothing but hail has those two
+    components zero, which the reference turns into NaN (scattering_sz.py:110) and with them ZH, ZV, ZDR and RHOHV, while
+    a gate that also holds another class is finite.  No node of that table qualifies for the combined columns, the
+    other classes' nodes do, so the gates of the beam mix both forms of unit."""
+    conf = O.make_config(microphysics={'scheme': 2}, attenuation={'correction': 1}, doppler={'scheme': 1},
+                         radar={'radial_resolution': 500., 'frequency': 5.6})
+    tabs = dict(util.synthetic_lut_arrays(2, 5.6))
+    e, t, d, tab = tabs['H']
+    tab = tab.copy()
+    tab[..., 1] = 0.
+    tab[..., 2] = 0.
+    tabs['H'] = (e, t, d, tab)
+    eng = engine.Engine(conf, device=0)
+    eng.upload_luts({h: Lookup_table.from_arrays(*v) for h, v in tabs.items()})
+    nodes = eng.ctx.get_column_combination()
+    assert sorted(nodes) == ['G', 'R', 'S'], nodes
+    beams = syn.synthetic_beams(240, 9, 2, seed=4711, res=500., zero_frac=0.2, nan_tail=5, below_head=2)
+    for b in beams:
+        inside = np.isfinite(b['values']['T'])          # gates outside the model carry NaN in every variable
+        for k in ('QH_v', 'QNH_v'):
+            v = b['values'][k]
+            v[inside & ~(v > 0)] = v[v > 0].mean()
+        for h in 'RSG':                       # gates 60..119: hail only
+            b['values']['Q%s_v' % h][60:120] = 0.
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    with np.errstate(all='ignore'):
+        luts = {h: O.Lut(*v) for h, v in tabs.items()}
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf)
+    zh = np.asarray(want.values['ZH'])
+    assert np.isnan(zh[60:120]).all() and np.isfinite(np.asarray(want.values['AH'])[60:120]).all()
+    assert np.isfinite(zh[130:200]).any()
+    check_obs(obs, want.values, 'zero column', 500.)
+    np.testing.assert_array_equal(mask, want.mask)
+
+
 def omitted_share_of_observable_combinations(tab, d_axis, mu, nu, cut_e, rng, n_samples=400):
     """What the certificate of a term cutoff claims, checked by brute force in float64: for random table nodes and
     random slopes, the share of each quantity the observables are made of (scattering_sz.py:168-194) that lies beyond
