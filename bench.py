@@ -330,6 +330,9 @@ def main(argv=None):
     ap.add_argument('--turbulence', type=int, choices=[0, 1], default=0, help='C5: turbulence broadening of the spectrum')
     ap.add_argument('--host-batches', type=str, default=None, help='N,F: batch schedule of the host-delivery measurement (cpol_set_host_batching)')
     ap.add_argument('--batch-units', type=int, default=0, help='positions per internal batch (0 = library default)')
+    ap.add_argument('--shard-of', type=int, default=0, help='N = 1 only: simulate the share of the rays that one rank of an M-rank run '
+                    'takes (no process group, no gather): what a shard costs on its own; the line is not a volume measurement')
+    ap.add_argument('--shard-rank', type=int, default=0, help='which rank\'s share --shard-of takes')
     ap.add_argument('--small', action='store_true', help='reduced grid / volume (debugging only; result INVALID)')
     ap.add_argument('--stub-engine', action='store_true',
                     help='CPU stand-in for the kernels over gloo: rehearses launch, sharding and gather without GPUs (result INVALID)')
@@ -393,6 +396,8 @@ def main(argv=None):
 
     shards = parallel.all_shards(n_sweeps, rays_per_sweep, world) if strong else [np.arange(len(azs))] * world
     mine = shards[rank]
+    if args.shard_of and world == 1:
+        mine = parallel.all_shards(n_sweeps, rays_per_sweep, args.shard_of)[args.shard_rank]
     R = len(mine)
     az_t, el_t = runner.angles(azs[mine], elv[mine])
     gather = strong and (world > 1 or args.rehearse_gather)
@@ -551,7 +556,7 @@ def main(argv=None):
                 'host_bytes_per_step': int(sum(v.numel() * v.element_size() for v in hb.values()))}
 
     if rank == 0:
-        gates_per_step = len(azs) * G * (1 if strong else world)
+        gates_per_step = (len(mine) if (args.shard_of and world == 1) else len(azs)) * G * (1 if strong else world)
         roofline = stage = None
         extra = {}
         if tim is not None:
@@ -612,6 +617,7 @@ def main(argv=None):
                                                     if tim['doppler_units'] else None)}
         invalid = ' [SMALL DEBUG RUN - INVALID]' if args.small else ''
         invalid += ' [STUB ENGINE, NO KERNELS - INVALID]' if args.stub_engine else ''
+        invalid += ' [SHARE OF RANK %d OF %d ONLY - NOT A VOLUME]' % (args.shard_rank, args.shard_of) if (args.shard_of and world == 1) else ''
         scan = '%d elevations x %d azimuths' % (n_sweeps, rays_per_sweep) if wl['kind'] == 'ppi' else \
             'RHI, %d azimuth(s) x %d elevations' % (n_sweeps, rays_per_sweep)
         line = {
