@@ -1662,6 +1662,10 @@ __device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, co
     if (spare) boff[NG - 1] = LDS_ZERO / 4 + dr;
     const int npass = (cnt + 31) >> 5;
     unsigned wsum = 0, own = 0;
+    // at the end of a pass the lane with residue dr stores the sums of unit (ug, dr) of either set; that unit's
+    // record was read by the lanes (ug, any residue, dr)
+    const bool dr_odd = dr & 1, dr_high = dr & 2;
+    const int rec_lane = ug * 16 + dr * 5;
     auto mfma4 = [](float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); };
 
     // passes of 32 units in cutoff order, two sets of 16; the waves take them in snake order (0 1 2 ... 7 7 6 ... 0
@@ -1677,6 +1681,7 @@ __device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, co
         if (ua < cnt) ra = urec[start + ua];
         if (ub < cnt) rb = urec[start + ub];
         const int nqa = __float_as_int(ra.z), nqb = __float_as_int(rb.z);      // quads the lane's units take part in
+        const int slot_a = __shfl(__float_as_int(ra.w), rec_lane), slot_b = __shfl(__float_as_int(rb.w), rec_lane);
         const float ha = ra.x, la = ra.y, hb = rb.x, lb = rb.y;
         // Units come in cutoff order, so the first set ends no later than the second begins: both sets run up to
         // the quad count of the first set's last unit, the second alone from there to that of its own last unit.
@@ -1817,40 +1822,50 @@ __device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, co
             }
         }
         // The four residues' partial sums meet (rotations by eight and by four lanes inside each row of 16 lanes, an
-        // order of additions that does not depend on the lane), then the
-        // lane with residue dr keeps register dr: unit (ug, dr) of the set, column 4 g + (lane & 3).  Result rows of
-        // 16 floats, each 16-byte piece written by four neighbouring lanes; with twelve columns the fourth piece is
-        // zeros, so that every row is written whole.
+        // order of additions that does not depend on the lane), then the lane with residue dr keeps register dr: unit
+        // (ug, dr) of the set, column 4 g + (lane & 3).  A result row's 16-byte pieces are written by four neighbouring
+        // lanes each; with twelve columns in rows of 16 floats the fourth piece is zeros, so that every row is written
+        // whole.
         {
-            auto finish = [&](int base, const f32x4 *acc) {
-                const int un = base + ug * 4 + dr;
+            auto finish = [&](int base, const f32x4 *acc, int uslot) {
                 if (base >= cnt) return;                 // wave-uniform: the set is empty
-                const long uslot = un < cnt ? (long)__float_as_int(urec[start + un].w) : 0;
-                const long row = uslot * ROW;
+                const bool live = base + ug * 4 + dr < cnt;
+                float *row = psd_out + (long)uslot * ROW + r4;
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
+                    // (p_dr + p_dr+2) + (p_dr+1 + p_dr+3): the same value in all four lanes, whichever stores it.  One
+                    // instruction per addition (the rotated operand through the DPP modifier), in one block: the
+                    // instructions of a stage are independent, and a result is read three instructions after it is
+                    // written (the wait states a DPP read of a fresh register needs); the leading s_nop covers the
+                    // accumulators' way out of the matrix pipe.
                     float t[4];
-#pragma unroll
-                    for (int v = 0; v < 4; v++) {
-                        float x = acc[g][v];
-                        // (p_dr + p_dr+2) + (p_dr+1 + p_dr+3): the same value in all four lanes, whichever stores it
-                        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));      // row_ror:8
-                        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));      // row_ror:4
-                        t[v] = x;
-                    }
-                    const float val = dr == 0 ? t[0] : dr == 1 ? t[1] : dr == 2 ? t[2] : t[3];
-                    if (un < cnt) {
-                        if (4 * g < ROW) psd_out[row + 4 * g + r4] = val;
-                        else psd_hi[uslot * 4 + r4] = val;          // columns 8..11 beside rows of eight floats
+                    asm volatile("s_nop 7\n\t"
+                                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_nop 1"
+                                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3])
+                                 : "v"(acc[g][0]), "v"(acc[g][1]), "v"(acc[g][2]), "v"(acc[g][3]));
+                    const float lo = dr_odd ? t[1] : t[0], hi = dr_odd ? t[3] : t[2];
+                    const float val = dr_high ? hi : lo;
+                    if (live) {
+                        if (4 * g < ROW) row[4 * g] = val;
+                        else psd_hi[(long)uslot * 4 + r4] = val;          // columns 8..11 beside rows of eight floats
                     }
                 }
-                if (NG * 4 < ROW && un < cnt) {
+                if (NG * 4 < ROW && live) {
 #pragma unroll
-                    for (int g = NG; g < ROW / 4; g++) psd_out[row + 4 * g + r4] = 0.f;
+                    for (int g = NG; g < ROW / 4; g++) row[4 * g] = 0.f;
                 }
             };
-            finish(u0, acca);
-            finish(u0 + 16, accb);
+            finish(u0, acca, slot_a);
+            finish(u0 + 16, accb, slot_b);
         }
     }
     if (work) {                                       // wave-uniform count of evaluated unit x quad steps
