@@ -1511,16 +1511,19 @@ void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, co
 }
 
 // =============================================================================
-// PSD integration (scattering_sz.py:76-103): for every unit of one (class, e-node,
-// t-node) bucket   r[k] = sum_d  sz[d][k] * D_d^mu * exp(-lambda * D_d^nu),  k < 12
-// as an [units x 1024] . [1024 x 16] contraction on the f32 matrix cores
-// (v_mfma_f32_16x16x4_f32).  The bucket's table slice lives in LDS; every lane
-// generates one N(D) value per MFMA (A operand), so nothing is computed twice.
+// PSD integration (scattering_sz.py:76-103): for every unit of one (form, class, e-node,
+// t-node) bucket   r[k] = sum_d  B'[d][k] * exp(-lambda * (D_d^nu - D_0^nu)),  B' = table column x D^mu,
+// as an [units x 1024] . [1024 x NC] contraction on the f32 matrix cores
+// (v_mfma_f32_4x4x1_16b_f32, NC / 4 instructions per 16 units x 4 diameters).  NC = 12: the twelve
+// scattering components; 8: the seven combinations of them the observables are made of
+// (get_pol_from_sz, scattering_sz.py:168-194); 14: the components and the two Doppler scheme-2 moments.
+// The bucket's table slice lives in LDS; every lane generates one N(D) value per step and set of
+// 16 units (A operand), so nothing is computed twice.
 // exp(-lambda (D^nu - D_0^nu)) is an exact float32 zero beyond a unit's cutoff diameter
-// (psd_cutoff_x): the workgroup orders its units by that cutoff, stages only the part of
-// the slice its largest cutoff needs and runs passes of 32 units, each up to the cutoff of
-// its last unit.  The skipped terms are exact zeros, so a unit's sums do not depend on
-// which units share its pass.
+// (psd_cutoff_x; earlier where the class's tables are certified for it): the workgroup orders its
+// units by that cutoff, stages only the part of the slice its largest cutoff needs and runs passes
+// of 32 units, two sets of 16, each set up to the cutoff of its last unit.  A unit's terms past its
+// own cutoff are set to zero, so its sums do not depend on which units share its pass.
 // =============================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
