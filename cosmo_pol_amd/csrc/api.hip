@@ -560,8 +560,9 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
     ct.dop_shared = shared ? 1 : 0;
     ct.ncol = shared ? 14 : 12;
     ct.n_kinds = (dop2 && !shared) ? 2 : 1;
-    // the combined columns (ClassTable::comb) hold the polarimetric quantities only
-    const bool want_comb = ctx->combine_columns && !shared;
+    // the combined columns (ClassTable::comb); when the Doppler moments ride on the polarimetric units, the spare
+    // column of the combined image carries the second one
+    const bool want_comb = ctx->combine_columns;
     for (int h = 0; h < ct.n_cls; h++) {
         LutDev &L = ctx->lut[h];
         const long nslice = (long)L.n_e * L.n_t;
@@ -592,7 +593,7 @@ static int build_class_table(cpol_ctx *ctx, ClassTable &ct, bool allow_build)
                 HIPCHK(ctx, hipMalloc((void **)&L.table_comb, (size_t)nslice * 1024 * CPOL_N_COMB * sizeof(float)));
                 HIPCHK(ctx, hipMalloc((void **)&L.node_floor, (size_t)nslice * sizeof(float)));
                 launch_build_image(ctx->stream, L.raw, L.d_axis, L.table_comb, L.xq, nslice, CPOL_N_COMB, L.psd.mu, L.psd.nu,
-                                   0, 0, 0., 0., 0., xref_of(L, L.psd.nu));
+                                   shared ? 1 : 0, 0, L.psd_dop.mu, L.psd_dop.alpha, L.psd_dop.beta, xref_of(L, L.psd.nu));
                 launch_node_floor(ctx->stream, L.raw, L.d_axis, nslice, L.psd.mu, L.node_floor);
                 std::vector<float> fl((size_t)nslice);
                 HIPCHK(ctx, hipMemcpyAsync(fl.data(), L.node_floor, fl.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -711,7 +712,7 @@ static int ensure_physics(cpol_ctx *ctx, const ClassTable &ct, long nu)
     // result rows of the polarimetric units: 16 floats, or with combined columns 8 and, for the units that take all
     // twelve columns, 4 more beside them
     TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * (ct.comb ? CPOL_N_COMB : CPOL_N_COL) * sizeof(float)));
-    if (ct.comb) TRY(ensure(ctx, ctx->w->b_psd_hi, (size_t)nu * ct.n_cls * 4 * sizeof(float)));
+    if (ct.comb) TRY(ensure(ctx, ctx->w->b_psd_hi, (size_t)nu * ct.n_cls * (ct.dop_shared ? 8 : 4) * sizeof(float)));
     if (ct.n_kinds == 2) TRY(ensure(ctx, ctx->w->b_dop, (size_t)nu * ct.n_cls * sizeof(float2)));
     TRY(ensure(ctx, ctx->w->b_cbkt, (size_t)((nslots + CPOL_CHUNK_UNITS - 1) / CPOL_CHUNK_UNITS + nb + 1) * sizeof(int)));
     // counters, shard cursors, bucket offsets, chunk offsets, and the run totals of the two-level scan (launch_scan)
@@ -793,6 +794,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     op.row = ct.comb ? CPOL_N_COMB : CPOL_N_COL;
     op.comb = ct.comb;
     op.nb_form = ct.n_cls * ct.ne_max * ct.nt_max;
+    op.hi = ct.dop_shared ? 8 : 4;
     Dop2In d2;
     memset(&d2, 0, sizeof(d2));
     if (ctx->cfg.doppler_scheme == 2) {
@@ -800,6 +802,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
         d2.lam = (const float2 *)ctx->w->b_lam.p; d2.n0d = (const double *)ctx->w->b_n0d.p;
         d2.dop_out = (const float2 *)ctx->w->b_dop.p;
         d2.n_cls = ct.n_cls; d2.ne_max = ct.ne_max; d2.nt_max = ct.nt_max; d2.shared = ct.dop_shared;
+        d2.comb = ct.comb; d2.nb_form = op.nb_form; d2.psd_hi = (const float *)ctx->w->b_psd_hi.p;
         if (ct.dop_shared) {       // columns 12, 13 of the 14-column image; d = 1023 is (q, k, s) = (63, 3, 3)
             d2.slice_floats = 1024 * 14;
             d2.at0[0] = 12 * 4; d2.at0[1] = 13 * 4;

@@ -129,6 +129,7 @@ struct ObsParams {
     int    att_corr, doppler, sens_mode;
     int    row;                    // floats per result row of the PSD integration: 16, or 8 with combined columns
     int    comb, nb_form;          // combined columns in use; keys from nb_form on are units in the twelve-column form
+    int    hi;                     // floats per unit in psd_hi
     double sens0, sens1, res_d;
 };
 
@@ -268,6 +269,8 @@ struct Dop2In {                    // inputs of the Doppler scheme-2 reduction i
     const double *n0d;
     const float2 *dop_out;         // results of the separate Doppler units, indexed like their polarimetric twins
     int n_cls, ne_max, nt_max, shared;
+    int comb, nb_form;             // as in ObsParams
+    const float *psd_hi;           // columns 8.. of the units that take all columns (shared: 12, 13 at [4], [5] of 8 floats)
     int slice_floats;              // floats per (e, t) node of that image
     int at0[2], at1[2];            // offsets of the two Doppler columns at d = 0 and d = 1023 inside a node
     const float *img[CPOL_MAX_CLASSES];   // table image holding the Doppler columns

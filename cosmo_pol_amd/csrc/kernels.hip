@@ -765,7 +765,8 @@ void launch_interp(hipStream_t s, const ModelView &mv, long n, const float *coor
 //   B'[d][12]      = rcs[d] * D^mu_d,  B'[d][13] = rcs[d] * v(D) * D^mu_d     (doppler_sz.py:192,218-220)
 // with rcs = 2 pi (sz0 - sz1 - sz2 + sz3) and v = alpha D^beta in float32 as in the reference.
 // ncol = CPOL_N_COMB (8): the image of the combined columns instead,
-//   B'[d][0..6] = (h, v, s4 + s7, s6 - s5, s10 - s8, s11, s9)[d] * D^mu,  B'[d][7] = 0.
+//   B'[d][0..6] = (h, v, s4 + s7, s6 - s5, s10 - s8, s11, s9)[d] * D^mu,  B'[d][7] = 0, or with with_dop the second
+//   Doppler moment (the first is 2 pi B'[d][0]).
 // xq[(q*4 + k)*4 + s] = D^nu - D_0^nu in the same permuted order.
 // =============================================================================
 __global__ void k_build_image(const float *__restrict__ raw, const float *__restrict__ d_axis, float *__restrict__ img,
@@ -788,6 +789,12 @@ __global__ void k_build_image(const float *__restrict__ raw, const float *__rest
         const double g = j == 0 ? ((z[0] - z[1]) - z[2]) + z[3] : j == 1 ? ((z[0] + z[1]) + z[2]) + z[3] : j == 2 ? z[4] + z[7]
                        : j == 3 ? z[6] - z[5] : j == 4 ? z[10] - z[8] : j == 5 ? z[11] : j == 6 ? z[9] : 0.;
         val = (float)(g * pow((double)D, mu));
+        if (j == 7 && with_dop) {
+            // the second Doppler scheme-2 moment, rcs v(D) D^mu_d, as column 13 of the 14-column image holds it; the
+            // first, rcs D^mu_d, is 2 pi times column 0 when the Doppler PSD is the polarimetric one (mu_d = mu)
+            float rcs = (float)(2 * M_PI) * (((src[0] - src[1]) - src[2]) + src[3]);
+            val = (rcs * ((float)alpha_d * powf(D, (float)beta_d))) * (float)pow((double)D, mu_d);
+        }
     }
     else if (j < CPOL_N_SZ) val = zero_pol ? 0.f : src[j] * (float)pow((double)D, mu);
     else if (!with_dop) val = 0.f;
@@ -1539,8 +1546,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two column groups exchanged, so that the 16 distinct words of a read fall into 16 different bank quarters).
 //
 // One chunk of <= CPOL_CHUNK_UNITS units of one bucket, integrated over an image of NC columns.  ROW floats per
-// result row in psd_out; with ROW = 8 columns 8..11 of a twelve-column unit go to psd_hi (4 floats per unit).
-template <int NC, int ROW>
+// result row in psd_out; with ROW = 8 the columns from 8 on of a unit that takes all columns go to psd_hi (HI floats
+// per unit: 4, or 8 when the Doppler moments are columns 12 and 13).
+template <int NC, int ROW, int HI>
 __device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, const float gstep, const bool cut_ok, const float cut_e,
                                                 const int ie, const int it, const int start, int cnt, const int *__restrict__ sorted,
                                                 float4 *urec, const float2 *__restrict__ lam, float *__restrict__ psd_out,
@@ -1859,7 +1867,7 @@ __device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, co
                     const float val = dr_high ? hi : lo;
                     if (live) {
                         if (4 * g < ROW) row[4 * g] = val;
-                        else psd_hi[(long)uslot * 4 + r4] = val;          // columns 8..11 beside rows of eight floats
+                        else psd_hi[(long)uslot * HI + (4 * g - ROW) + r4] = val;          // the columns from 8 on beside rows of eight floats
                     }
                 }
                 if (NG * 4 < ROW && live) {
@@ -1881,30 +1889,32 @@ __device__ __forceinline__ void integrate_chunk(float *lds, const LutView lv, co
     }
 }
 
-// NCA: columns of the image that planes [0, n_cls) are integrated over; NCB: 0, or the columns of the image of the
-// planes [n_cls, 2 n_cls) when the configuration has two forms of polarimetric unit (ClassTable::comb: NCA = 8
-// combined columns, NCB = 12).  Three workgroups per CU up to 12 columns (48 KB slice), two with 14.
-template <int NCA, int NCB>
+// The chunks of the buckets [b_lo, b_hi).  NCA: columns of the image that planes [0, n_cls) are integrated over, the
+// image of the combined columns when A_COMB; NCB: 0, or the columns of the image of the planes [n_cls, 2 n_cls) when
+// one launch takes both forms of polarimetric unit (ClassTable::comb: NCA = 8 combined columns, NCB = 12).  ROW, HI:
+// see integrate_chunk.  Three workgroups per CU up to 12 columns (48 KB slice), two with 14.
+template <int NCA, int NCB, int ROW, int HI, bool A_COMB>
 __global__ __launch_bounds__(INTEG_THREADS, ((NCA > NCB ? NCA : NCB) <= 12 ? 3 : 2) * (INTEG_THREADS / 256))
-void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int *__restrict__ chunk_off,
+void k_integrate(ClassTable ct, int b_lo, int b_hi, const int *__restrict__ offs, const int *__restrict__ chunk_off,
                  const int *__restrict__ chunk_bucket, const int *__restrict__ sorted, float4 *urec, const float2 *__restrict__ lam,
                  float *__restrict__ psd_out, float *__restrict__ psd_hi, unsigned long long *__restrict__ work)
-{   // nb = number of polarimetric buckets (the separate Doppler units' buckets follow them)
+{
     constexpr int NCMAX = NCA > NCB ? NCA : NCB;
-    constexpr int ROW = NCB ? CPOL_N_COMB : CPOL_N_COL;
     __shared__ __attribute__((aligned(16))) float lds[1024 * NCMAX + 64 + 1024];
 
     // XCD-aware chunk order: the workgroups of one XCD (blockIdx % 8) take runs of INTEG_XCD_RUN consecutive
     // chunks, i.e. mostly the same table slice, so a slice is fetched into one L2; the runs go round the XCDs
     // because a chunk's cost depends on its class and node (cutoffs), and a contiguous eighth of the chunk
     // list per XCD would leave some XCDs with all the expensive ones.
-    const unsigned total = (unsigned)chunk_off[nb];
+    const int c_lo = chunk_off[b_lo];
+    const unsigned total = (unsigned)(chunk_off[b_hi] - c_lo);
     const unsigned xcd = blockIdx.x % 8, kx = blockIdx.x / 8;
-    const unsigned cid = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
-    if (cid >= total) return;
+    const unsigned rel = ((kx / INTEG_XCD_RUN) * 8 + xcd) * INTEG_XCD_RUN + kx % INTEG_XCD_RUN;
+    if (rel >= total) return;
+    const int cid = c_lo + (int)rel;
 
     const int bkt = chunk_bucket[cid];              // bucket of this chunk (k_fill_chunks)
-    const int start = offs[bkt] + ((int)cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
+    const int start = offs[bkt] + (cid - chunk_off[bkt]) * CPOL_CHUNK_UNITS;
     int cnt = offs[bkt + 1] - start;
     if (cnt > CPOL_CHUNK_UNITS) cnt = CPOL_CHUNK_UNITS;
 
@@ -1916,11 +1926,13 @@ void k_integrate(ClassTable ct, int nb, const int *__restrict__ offs, const int 
     const bool cut_ok = ct.cut_ok[h];                      // D^nu ascending: N(D) = 0 past a unit's cutoff
     const float cut_e = ct.cut_e[h];
     if (NCB && plane >= ct.n_cls)
-        integrate_chunk<NCB ? NCB : NCA, ROW>(lds, ct.lut[h], gstep, cut_ok, cut_e, ie, it, start, cnt, sorted, urec, lam, psd_out, psd_hi, work);
+        integrate_chunk<NCB ? NCB : NCA, ROW, HI>(lds, ct.lut[h], gstep, cut_ok, cut_e, ie, it, start, cnt, sorted, urec, lam, psd_out, psd_hi, work);
     else
-        integrate_chunk<NCA, ROW>(lds, NCB ? ct.lut_comb[h] : ct.lut[h], gstep, cut_ok, cut_e, ie, it, start, cnt, sorted, urec, lam, psd_out, psd_hi, work);
+        integrate_chunk<NCA, ROW, HI>(lds, A_COMB ? ct.lut_comb[h] : ct.lut[h], gstep, cut_ok, cut_e, ie, it, start, cnt, sorted, urec, lam, psd_out,
+                                      psd_hi, work);
 }
 
+// nb: number of polarimetric buckets (the separate Doppler units' buckets follow them).
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, float4 *urec, const float2 *lam,
                       float *psd_out, float *psd_hi, unsigned long long *work)
@@ -1928,15 +1940,25 @@ void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int 
     if (max_chunks <= 0) return;
     max_chunks = (max_chunks + 8 * INTEG_XCD_RUN - 1) / (8 * INTEG_XCD_RUN) * (8 * INTEG_XCD_RUN);   // whole rounds of runs
     const dim3 grid((unsigned)max_chunks), block(INTEG_THREADS);
-    if (ct.comb)
-        hipLaunchKernelGGL((k_integrate<CPOL_N_COMB, 12>), grid, block, 0, s, ct, nb, offs, chunk_off, chunk_bucket, sorted, urec, lam,
-                           psd_out, psd_hi, work);
+    const int nbf = ct.n_cls * ct.ne_max * ct.nt_max;          // buckets of one form
+    if (ct.comb && !ct.dop_shared)
+        hipLaunchKernelGGL((k_integrate<CPOL_N_COMB, 12, CPOL_N_COMB, 4, true>), grid, block, 0, s, ct, 0, nb, offs, chunk_off, chunk_bucket,
+                           sorted, urec, lam, psd_out, psd_hi, work);
+    else if (ct.comb) {
+        // the Doppler moments ride on the polarimetric units: the combined image carries the second one, the units
+        // that take all columns take the 14-column image, whose slice lets two workgroups share a CU where the
+        // combined one lets three - so the two forms are launches of their own (the second nearly empty)
+        hipLaunchKernelGGL((k_integrate<CPOL_N_COMB, 0, CPOL_N_COMB, 8, true>), grid, block, 0, s, ct, 0, nbf, offs, chunk_off, chunk_bucket,
+                           sorted, urec, lam, psd_out, psd_hi, work);
+        hipLaunchKernelGGL((k_integrate<14, 0, CPOL_N_COMB, 8, false>), grid, block, 0, s, ct, nbf, nb, offs, chunk_off, chunk_bucket,
+                           sorted, urec, lam, psd_out, psd_hi, work);
+    }
     else if (ct.ncol == 12)
-        hipLaunchKernelGGL((k_integrate<12, 0>), grid, block, 0, s, ct, nb, offs, chunk_off, chunk_bucket, sorted, urec, lam,
-                           psd_out, psd_hi, work);
+        hipLaunchKernelGGL((k_integrate<12, 0, CPOL_N_COL, 0, false>), grid, block, 0, s, ct, 0, nb, offs, chunk_off, chunk_bucket, sorted, urec,
+                           lam, psd_out, psd_hi, work);
     else
-        hipLaunchKernelGGL((k_integrate<14, 0>), grid, block, 0, s, ct, nb, offs, chunk_off, chunk_bucket, sorted, urec, lam,
-                           psd_out, psd_hi, work);
+        hipLaunchKernelGGL((k_integrate<14, 0, CPOL_N_COL, 0, false>), grid, block, 0, s, ct, 0, nb, offs, chunk_off, chunk_bucket, sorted, urec,
+                           lam, psd_out, psd_hi, work);
 }
 
 // =============================================================================
@@ -2200,7 +2222,13 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
         any = true;
         double s12, s13;
         if (d2.shared) {
-            s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13];
+            if (!d2.comb) { s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13]; }
+            else if (k < d2.nb_form) {
+                // a unit in the combined form: column 7 holds the second moment, the first is 2 pi times column 0
+                s12 = (double)(float)(2 * M_PI) * (double)psd_out[pslot * CPOL_N_COMB];
+                s13 = (double)psd_out[pslot * CPOL_N_COMB + 7];
+            }
+            else { s12 = (double)d2.psd_hi[pslot * 8 + 4]; s13 = (double)d2.psd_hi[pslot * 8 + 5]; }      // columns 12, 13
         }
         else { const float2 t = d2.dop_out[pslot]; s12 = (double)t.x; s13 = (double)t.y; }
         if (d2.shared) {
@@ -2248,7 +2276,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     // the twelve sums of one unit: a row of 16 floats, or (combined columns in use) eight floats and four beside them
     auto twelve = [&](long slot, float *vv) {
         const float4 *p = (const float4 *)(psd_out + slot * op.row);
-        const float4 v0 = p[0], v1 = p[1], v2 = op.comb ? *(const float4 *)(psd_hi + slot * 4) : p[2];
+        const float4 v0 = p[0], v1 = p[1], v2 = op.comb ? *(const float4 *)(psd_hi + slot * op.hi) : p[2];
         vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
         vv[8] = v2.x; vv[9] = v2.y; vv[10] = v2.z; vv[11] = v2.w;
     };

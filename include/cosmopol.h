@@ -161,8 +161,9 @@ int cpol_get_term_cutoff(cpol_ctx *ctx, float exponent[CPOL_MAX_CLASSES]);
  * accumulated in float64: none of its components can be an exact zero unless nonzero contributions cancel exactly,
  * which needs unrelated floats to be exact negatives of each other and is the one case not reproduced; its
  * observables differ from the reference's float32 accumulation of the components by that accumulation's own rounding
- * (a few 1e-7 of a component).  on = 0: all units over all twelve columns.  The setting does not apply when the two
- * Doppler scheme-2 moments ride on the polarimetric units (1-moment input), which then take all columns.
+ * (a few 1e-7 of a component).  on = 0: all units over all twelve columns.  When the two Doppler scheme-2 moments ride
+ * on the polarimetric units (1-moment input, doppler_sz.py:192,218-220) the spare eighth column carries the second,
+ * sum N rcs v, and the first, sum N rcs, is 2 pi times the first combination, rcs = 2 pi (s0 - s1 - s2 + s3).
  * cpol_get_column_combination reports per class how many table nodes qualify (all 0: no unit takes the combined
  * columns).  No counterpart in the reference. */
 int cpol_set_column_combination(cpol_ctx *ctx, int on);
