@@ -2209,6 +2209,8 @@ void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, 
 // Doppler scheme 2 (doppler_sz.py:155-231) for one (ray, sub-beam, gate): RCS- and PSD-weighted mean fall
 // speed over the classes from the two extra columns of the PSD integration, unit-spacing trapezoid rule
 // (sum minus half of the end terms, :219-220), air-density correction and projection on the beam (:23,231).
+// SHARED: the two moments ride on the polarimetric units (1-moment input); COMB: combined columns in use.
+template <bool COMB, bool SHARED>
 __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__restrict__ key, const float *__restrict__ psd_out,
                                          long nu, long u, long rb, int G)
 {
@@ -2216,13 +2218,13 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
     bool any = false;
     for (int h = 0; h < d2.n_cls; h++) {
         const long pslot = (long)h * nu + u;                            // polarimetric unit of the class
-        const long slot = d2.shared ? pslot : pslot + (long)d2.n_cls * nu;      // unit carrying the Doppler PSD
+        const long slot = SHARED ? pslot : pslot + (long)d2.n_cls * nu;      // unit carrying the Doppler PSD
         int k = key[pslot];
         if (k < 0) continue;
         any = true;
         double s12, s13;
-        if (d2.shared) {
-            if (!d2.comb) { s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13]; }
+        if (SHARED) {
+            if (!COMB) { s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13]; }
             else if (k < d2.nb_form) {
                 // a unit in the combined form: column 7 holds the second moment, the first is 2 pi times column 0
                 s12 = (double)(float)(2 * M_PI) * (double)psd_out[pslot * CPOL_N_COMB];
@@ -2231,7 +2233,7 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
             else { s12 = (double)d2.psd_hi[pslot * 8 + 4]; s13 = (double)d2.psd_hi[pslot * 8 + 5]; }      // columns 12, 13
         }
         else { const float2 t = d2.dop_out[pslot]; s12 = (double)t.x; s13 = (double)t.y; }
-        if (d2.shared) {
+        if (SHARED) {
             // the MFMA columns hold plain sums: take half of the end terms off (unit-spacing trapezoid rule)
             const int it = k % d2.nt_max, ie = (k / d2.nt_max) % d2.ne_max;
             const float *img = d2.img[h] + (long)(ie * d2.n_t[h] + it) * d2.slice_floats;
@@ -2262,6 +2264,9 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
 // the threads wait on dependent loads, so a seventh wavefront per SIMD is worth the 72-register limit.
 #define GR_THREADS 64
 #define GR_OCC 7
+// COMB: combined columns in use (rows of eight floats, two forms of unit); SHARED: the Doppler scheme-2 moments ride on
+// the polarimetric units.
+template <bool COMB, bool SHARED>
 __global__ __launch_bounds__(GR_THREADS, GR_OCC)
 void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restrict__ key, const double *__restrict__ coef,
                    const float *__restrict__ psd_out, const float *__restrict__ psd_hi, const signed char *__restrict__ mask,
@@ -2276,7 +2281,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     // the twelve sums of one unit: a row of 16 floats, or (combined columns in use) eight floats and four beside them
     auto twelve = [&](long slot, float *vv) {
         const float4 *p = (const float4 *)(psd_out + slot * op.row);
-        const float4 v0 = p[0], v1 = p[1], v2 = op.comb ? *(const float4 *)(psd_hi + slot * op.hi) : p[2];
+        const float4 v0 = p[0], v1 = p[1], v2 = COMB ? *(const float4 *)(psd_hi + slot * op.hi) : p[2];
         vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
         vv[8] = v2.x; vv[9] = v2.y; vv[10] = v2.z; vv[11] = v2.w;
     };
@@ -2294,7 +2299,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
         comb_gate = comb_gate || m == CPOL_MASK_COMB;
         msum += m == CPOL_MASK_COMB ? 0. : (double)m;
     }
-    if (comb_gate) {
+    if (COMB && comb_gate) {
         double C[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) C[k] = 0.;
@@ -2365,7 +2370,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     for (int b = 0; b < B; b++) {
         long u = ((long)r * B + b) * G + g;
         if (op.doppler == 1 || op.doppler == 2) {
-            double pw = op.doppler == 2 ? doppler2_radial(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
+            double pw = op.doppler == 2 ? doppler2_radial<COMB, SHARED>(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
             double w = wsub[b];
             sw += (pw != pw) ? 0. : w;
             double tt = pw * w;
@@ -2486,8 +2491,13 @@ void launch_observables(hipStream_t s, const ObsParams &op, int n_rays, long nu,
                         long ray0, double *mask_out, double *rvel_out, const Dop2In &d2, double *spectrum, int n_vel)
 {
     const long n = (long)n_rays * op.n_gates;
-    hipLaunchKernelGGL(k_gate_reduce, dim3((unsigned)((n + GR_THREADS - 1) / GR_THREADS)), dim3(GR_THREADS), 0, s, op, n_rays, nu, key, coef,
-                       psd_out, psd_hi, mask, weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2);
+    const dim3 grid((unsigned)((n + GR_THREADS - 1) / GR_THREADS)), block(GR_THREADS);
+#define CPOL_GR_LAUNCH(C, S) hipLaunchKernelGGL((k_gate_reduce<C, S>), grid, block, 0, s, op, n_rays, nu, key, coef, psd_out, psd_hi, mask, \
+                                                weight_per_sub, vr, obs, obs_plane, ray0, mask_out, rvel_out, d2)
+    const bool shared = op.doppler == 2 && d2.shared;
+    if (op.comb) { if (shared) CPOL_GR_LAUNCH(true, true); else CPOL_GR_LAUNCH(true, false); }
+    else { if (shared) CPOL_GR_LAUNCH(false, true); else CPOL_GR_LAUNCH(false, false); }
+#undef CPOL_GR_LAUNCH
     hipLaunchKernelGGL(k_ray_scan, dim3(n_rays), dim3(64), 0, s, op, obs, obs_plane, ray0, rvel_out, spectrum,
                        n_vel);
 }
