@@ -85,7 +85,7 @@ def main():
         if "TA_TA_BUSY_sum" in fr and "SQ_BUSY_CYCLES" in fr:
             # TA_TA_BUSY_sum adds the 256 CUs' busy cycles, SQ_BUSY_CYCLES the 32 shader engines'
             t["k_front_ta_busy_frac"] = (fr["TA_TA_BUSY_sum"] / 256.) / (fr["SQ_BUSY_CYCLES"] / 32.)
-        gr = result["kernels"].get("k_gate_reduce", {})
+        gr = next((v for k, v in result["kernels"].items() if k.startswith("k_gate_reduce")), {})
         if "hbm_bytes_per_launch" in gr:
             t["k_gate_reduce_hbm_bytes_per_launch"] = gr["hbm_bytes_per_launch"]
         with open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w") as fh:
