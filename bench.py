@@ -308,7 +308,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20, help='timed volumes (a volume takes about 9 ms; the first one or two after a pause run slower)')
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=10, help='untimed volumes first (the clocks take a few volumes to settle after the set-up)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong',
                     help='strong (default): the rays of ONE volume are shared out over the ranks and gathered on rank 0; '
                          'weak: every rank simulates a whole volume of its own')

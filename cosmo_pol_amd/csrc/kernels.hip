@@ -2248,7 +2248,9 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
         vh += (a != a ? 0. : a);
         nn += (b != b ? 0. : b);
     }
-    double vhyd = any ? vh / nn : __builtin_nan("");
+    // no hydrometeors at the point: the fall speed is 0 / 0 and the radial velocity a NaN whatever the wind is
+    if (!any) return __builtin_nan("");
+    double vhyd = vh / nn;
     float rho = d2.vals[(long)CPOL_V_RHO * d2.plane + u];
     float rho0 = d2.vals[(long)CPOL_V_RHO * d2.plane + rb * G];
     vhyd *= (double)sqrtf(rho / rho0);
