@@ -186,7 +186,9 @@ class VolumeGather(object):
             if side is not None:
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record(side)
-            b['rows'].index_copy_(0, b['idx'], b['recv'].view(-1, b['recv'].shape[-1]))
+            # rows are whole multiples of eight bytes (_row_layout): moved as 64-bit words, an eighth of the elements
+            # a byte-wise indexed copy would handle
+            b['rows'].view(torch.int64).index_copy_(0, b['idx'], b['recv'].view(-1, b['recv'].shape[-1]).view(torch.int64))
             if side is not None:
                 t1.record(side)
                 self.assemble_ms_events = (t0, t1)
