@@ -77,9 +77,11 @@ def mask_to_codes(mask, n_sub):
 
 
 def codes_to_mask(codes, n_sub):
+    """sum / n_sub with the values in [0, 1) set to 0, i.e. the sums 0 .. n_sub - 1: selected on the one-byte codes,
+    so that the float64 volume is written once."""
     import torch
-    m = codes.to(torch.float64) / n_sub
-    return torch.where((m >= 0) & (m < 1), torch.zeros_like(m), m)
+    keep = (codes < 0) | (codes >= n_sub)
+    return (codes * keep).to(torch.float64) / n_sub
 
 
 class VolumeGather(object):
