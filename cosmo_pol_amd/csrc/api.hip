@@ -709,6 +709,7 @@ static int ensure_physics(cpol_ctx *ctx, const ClassTable &ct, long nu)
     TRY(ensure(ctx, ctx->w->b_sorted, (size_t)nu * ct.n_cls * sizeof(int)));      // polarimetric units; their Doppler twins follow them
     TRY(ensure(ctx, ctx->w->b_urec, (size_t)nu * ct.n_cls * sizeof(float4)));          // the chunks' units in cutoff order
     TRY(ensure(ctx, ctx->w->b_rank, nslots * sizeof(int)));
+    TRY(ensure(ctx, ctx->w->b_uflag, (size_t)nu));
     // result rows of the polarimetric units: 16 floats, or with combined columns 8 and, for the units that take all
     // twelve columns, 4 more beside them
     TRY(ensure(ctx, ctx->w->b_psd, (size_t)nu * ct.n_cls * (ct.comb ? CPOL_N_COMB : CPOL_N_COL) * sizeof(float)));
@@ -754,8 +755,9 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     } else if (ctx->cfg.doppler_scheme == 1)
         launch_vr1(ctx->stream, ct, nu, G, vals, plane, elev, phi, (double *)ctx->w->b_vr.p);
     launch_scan(ctx->stream, nb, nb_pol, hist, offs, cursor, chunk_off, (int *)ctx->w->b_cbkt.p);
+    // (keys below n_cls x nodes are units in the combined form when there are two forms)
     launch_scatter(ctx->stream, nu, ct.n_cls, (const cpol_key_t *)ctx->w->b_key.p, (const int *)ctx->w->b_rank.p, offs, cursor,
-                   (int *)ctx->w->b_sorted.p);
+                   (int *)ctx->w->b_sorted.p, ct.comb ? ct.n_cls * ct.ne_max * ct.nt_max : 0, (unsigned char *)ctx->w->b_uflag.p);
     }
     const bool count_work = ctx->timing && !ctx->arena;
     if (count_work) {
@@ -795,6 +797,7 @@ static int run_physics(cpol_ctx *ctx, const ClassTable &ct, int nr, int B, int G
     op.comb = ct.comb;
     op.nb_form = ct.n_cls * ct.ne_max * ct.nt_max;
     op.hi = ct.dop_shared ? 8 : 4;
+    op.uflag = (const unsigned char *)ctx->w->b_uflag.p;
     Dop2In d2;
     memset(&d2, 0, sizeof(d2));
     if (ctx->cfg.doppler_scheme == 2) {

@@ -130,6 +130,7 @@ struct ObsParams {
     int    row;                    // floats per result row of the PSD integration: 16, or 8 with combined columns
     int    comb, nb_form;          // combined columns in use; keys from nb_form on are units in the twelve-column form
     int    hi;                     // floats per unit in psd_hi
+    const unsigned char *uflag;    // per point: bit h = class h holds a unit, bit 4 + h = that unit takes the combined columns
     double sens0, sens1, res_d;
 };
 
@@ -168,7 +169,7 @@ struct cpol_ctx {
     struct Buf { void *p = nullptr; size_t cap = 0; };
     struct Work {
         Buf b_S, b_H, b_E, b_lat, b_lon, b_coords, b_line, b_phi, b_vals, b_mask, b_key, b_lam, b_coef,
-            b_sorted, b_urec, b_rank, b_psd, b_psd_hi, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
+            b_sorted, b_urec, b_rank, b_uflag, b_psd, b_psd_hi, b_dop, b_cbkt, b_n0d, b_vr, b_hist, b_stage, b_az, b_el, b_status,
             o_obs, o_rvel, o_spec, o_mask, o_lat, o_lon, o_dist, o_height, o_diag, t_a, t_b, t_c, t_d, t_e;
     };
     Work heap, arena_work;
@@ -230,7 +231,7 @@ void launch_sincos_deg(hipStream_t s, int n, const double *deg, double *sc);
 void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, int *cursor, int *chunk_off,
                  int *chunk_bucket);
 void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
-                    const int *cursor, int *sorted);
+                    const int *cursor, int *sorted, int nb_form, unsigned char *uflag);
 void launch_integrate(hipStream_t s, const ClassTable &ct, long max_chunks, int nb, const int *offs,
                       const int *chunk_off, const int *chunk_bucket, const int *sorted, float4 *urec, const float2 *lam,
                       float *psd_out, float *psd_hi, unsigned long long *work);

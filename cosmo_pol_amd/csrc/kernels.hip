@@ -1496,8 +1496,12 @@ void launch_scan(hipStream_t s, int nb, int nb_counted, int *hist, int *offs, in
 
 // Final position of every valid polarimetric unit = bucket start + start of its shard inside the bucket + the
 // rank the PSD set-up drew.  One thread per position, its (up to four) classes one after the other.
+// The thread also leaves the point's units in one byte (uflag: bit h = class h holds a unit, bit 4 + h = that unit's
+// key lies below nb_form, i.e. it takes the combined columns): the reduction of a gate walks its points by these
+// bytes, not by the keys of all classes.
 __global__ void k_scatter(long nu, int n_cls, const cpol_key_t *__restrict__ key, const int *__restrict__ rank,
-                          const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted)
+                          const int *__restrict__ offs, const int *__restrict__ cursor, int *__restrict__ sorted,
+                          int nb_form, unsigned char *__restrict__ uflag)
 {
     long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nu) return;
@@ -1508,13 +1512,18 @@ __global__ void k_scatter(long nu, int n_cls, const cpol_key_t *__restrict__ key
 #pragma unroll
     for (int h = 0; h < 4; h++)
         if (k[h] >= 0) sorted[offs[k[h]] + cursor[k[h] * CPOL_SORT_SHARDS + shard] + rank[(long)h * nu + u]] = (int)((long)h * nu + u);
+    unsigned flags = 0;
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+        if (k[h] >= 0) flags |= (1u | (k[h] < nb_form ? 16u : 0u)) << h;
+    uflag[u] = (unsigned char)flags;
 }
 
 void launch_scatter(hipStream_t s, long nu, int n_cls, const cpol_key_t *key, const int *rank, const int *offs,
-                    const int *cursor, int *sorted)
+                    const int *cursor, int *sorted, int nb_form, unsigned char *uflag)
 {
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, nu, n_cls, key, rank, offs, cursor,
-                       sorted);
+                       sorted, nb_form, uflag);
 }
 
 // =============================================================================
@@ -2212,16 +2221,16 @@ void launch_integrate_dop(hipStream_t s, const ClassTable &ct, long max_chunks, 
 // SHARED: the two moments ride on the polarimetric units (1-moment input); COMB: combined columns in use.
 template <bool COMB, bool SHARED>
 __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__restrict__ key, const float *__restrict__ psd_out,
-                                         long nu, long u, long rb, int G)
+                                         long nu, long u, long rb, int G, const unsigned char *__restrict__ uflag)
 {
     double vh = 0., nn = 0.;
-    bool any = false;
+    const unsigned uf = uflag[u];                                       // bit h: class h holds a unit at the point
+    if (!(uf & 15u)) return __builtin_nan("");       // no hydrometeors: the fall speed is 0 / 0 and the radial velocity a NaN whatever the wind is
     for (int h = 0; h < d2.n_cls; h++) {
         const long pslot = (long)h * nu + u;                            // polarimetric unit of the class
         const long slot = SHARED ? pslot : pslot + (long)d2.n_cls * nu;      // unit carrying the Doppler PSD
-        int k = key[pslot];
-        if (k < 0) continue;
-        any = true;
+        if (!((uf >> h) & 1u)) continue;
+        int k = SHARED ? (int)key[pslot] : 0;       // the table node, for the end terms of the columns of the matrix kernel
         double s12, s13;
         if (SHARED) {
             if (!COMB) { s12 = (double)psd_out[pslot * CPOL_N_COL + 12]; s13 = (double)psd_out[pslot * CPOL_N_COL + 13]; }
@@ -2248,8 +2257,6 @@ __device__ inline double doppler2_radial(const Dop2In &d2, const cpol_key_t *__r
         vh += (a != a ? 0. : a);
         nn += (b != b ? 0. : b);
     }
-    // no hydrometeors at the point: the fall speed is 0 / 0 and the radial velocity a NaN whatever the wind is
-    if (!any) return __builtin_nan("");
     double vhyd = vh / nn;
     float rho = d2.vals[(long)CPOL_V_RHO * d2.plane + u];
     float rho0 = d2.vals[(long)CPOL_V_RHO * d2.plane + rb * G];
@@ -2302,17 +2309,19 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
         msum += m == CPOL_MASK_COMB ? 0. : (double)m;
     }
     if (COMB && comb_gate) {
+        // sub-beam after sub-beam, the classes of a point by its flags
         double C[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) C[k] = 0.;
-        for (int h = 0; h < op.n_cls; h++)
-            for (int b = 0; b < B; b++) {
-                const long slot = (long)h * nu + ((long)r * B + b) * G + g;
-                const int kk = key[slot];
-                if (kk < 0) continue;
+        for (int b = 0; b < B; b++) {
+            const long u = ((long)r * B + b) * G + g;
+            const unsigned uf = op.uflag[u];         // bit h: class h holds a unit at the point; bit 4 + h: in the combined form
+            for (int h = 0; h < op.n_cls; h++) {
+                if (!((uf >> h) & 1u)) continue;
+                const long slot = (long)h * nu + u;
                 const double c = coef[slot];
                 double gq[7];
-                if (kk < op.nb_form) {
+                if ((uf >> (4 + h)) & 1u) {
                     const float4 *p = (const float4 *)(psd_out + slot * CPOL_N_COMB);
                     const float4 v0 = p[0], v1 = p[1];
                     gq[0] = v0.x; gq[1] = v0.y; gq[2] = v0.z; gq[3] = v0.w; gq[4] = v1.x; gq[5] = v1.y; gq[6] = v1.z;
@@ -2330,6 +2339,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
                     C[k] += (v != v ? 0. : v);           // nansum_arr: a NaN counts as zero (utilities.py:46-66)
                 }
             }
+        }
         bq = (float)C[0]; cq = (float)C[1]; a1 = (float)C[2]; a2 = (float)C[3]; kd = (float)C[4]; s11 = (float)C[5]; s9 = (float)C[6];
     } else {
         // every component as the reference accumulates it: float32 storage after every sub-beam (scattering_sz.py:38,
@@ -2372,7 +2382,7 @@ void k_gate_reduce(ObsParams op, int n_rays, long nu, const cpol_key_t *__restri
     for (int b = 0; b < B; b++) {
         long u = ((long)r * B + b) * G + g;
         if (op.doppler == 1 || op.doppler == 2) {
-            double pw = op.doppler == 2 ? doppler2_radial<COMB, SHARED>(d2, key, psd_out, nu, u, ((long)r * B + b), G) : vr[u];
+            double pw = op.doppler == 2 ? doppler2_radial<COMB, SHARED>(d2, key, psd_out, nu, u, ((long)r * B + b), G, op.uflag) : vr[u];
             double w = wsub[b];
             sw += (pw != pw) ? 0. : w;
             double tt = pw * w;

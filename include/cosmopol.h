@@ -289,7 +289,7 @@ int cpol_wait_async(cpol_ctx *ctx, int calls_back);
  * cpol_run_rays_dev, bit for bit, but the call allocates nothing: every workspace is a piece of one array of
  * 80 MiB that the library keeps in the device memory of each GPU it runs on until the process ends.  For that:
  *   - n_rays x sub-beams x n_gates must not exceed CPOL_STATIC_MAX_POSITIONS (CPOL_ERR_ARG otherwise).  That is the
- *     only size limit: a position takes at most 725 bytes of the array (2-moment input with Doppler scheme 2), 47.5 MB
+ *     only size limit: a position takes at most 726 bytes of the array (2-moment input with Doppler scheme 2), 47.5 MB
  *     at the limit, and outputs served from the array at most 76 bytes per gate; the sort counters take 520 bytes per
  *     bucket (lookup-table node x unit kind x unit form), and the library accepts at most 32768 buckets (17 MB; 15 MB
  *     for the reference's 46 x 39-node tables of four classes with Doppler units of their own and two forms of
