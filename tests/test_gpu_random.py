@@ -1,0 +1,46 @@
+"""GPU: cpol_observables_from_beams against the oracle on randomly drawn settings (microphysics scheme, Doppler
+scheme 0 / 1 / 2, 1 - 25 sub-beams, 1 - 400 gates, attenuation correction on or off, radial resolution, share of empty
+gates, contents left as they are or spread over ten decades).  The cases are fixed by their seeds; the bars are those
+of tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import cosmo_oracle as O
+from tests import synthetic as syn, util
+from tests.test_gpu_parity import beams_to_arrays, check_obs, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('case', range(16))
+def test_random_settings_vs_oracle(case):
+    rng = np.random.default_rng(7000 + case)
+    scheme = int(rng.integers(1, 3))
+    dscheme = int(rng.integers(0, 3))
+    n_sub = int(rng.choice([1, 3, 9, 25]))
+    n_gates = int(rng.integers(1, 400))
+    att = int(rng.integers(0, 2))
+    res = float(rng.choice([75., 250., 500.]))
+    seed = int(rng.integers(0, 1 << 30))
+    zero_frac = float(rng.uniform(0., 0.6))
+    conf = O.make_config(microphysics={'scheme': scheme}, attenuation={'correction': att}, doppler={'scheme': dscheme},
+                         radar={'radial_resolution': res, 'frequency': 5.6})
+    eng = make_engine(conf)
+    beams = syn.synthetic_beams(n_gates, n_sub, scheme, seed=seed, res=res, zero_frac=zero_frac,
+                                nan_tail=min(7, n_gates // 3), below_head=min(2, n_gates // 4))
+    if rng.uniform() < 0.4:
+        for b in beams:
+            for k, v in b['values'].items():
+                if k.startswith('Q') and k.endswith('_v'):
+                    v *= (10. ** rng.uniform(-8, 2, v.shape)).astype(np.float32)
+    obs, mask, rvel = eng.ctx.observables_from_beams(*beams_to_arrays(beams))
+    luts = util.oracle_luts(scheme, 5.6)
+    tag = 'scheme %d doppler %d sub-beams %d gates %d attenuation %d res %g' % (scheme, dscheme, n_sub, n_gates, att, res)
+    with np.errstate(all='ignore'):
+        # attenuation factors as correctly rounded float32 powers, which the kernel uses (see test_gpu_parity.py)
+        want = O.get_radar_observables(util.oracle_beams(beams), luts, conf, pow10=O.pow10_rounded)
+        check_obs(obs, want.values, tag, res)
+        np.testing.assert_array_equal(mask, want.mask)
+        if dscheme:
+            want_v = O.get_doppler_velocity(util.oracle_beams(beams), luts, conf)
+            util.assert_close(rvel, want_v.values['RVEL'], rtol=1e-5, atol=1e-6, name='RVEL')
